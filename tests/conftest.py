@@ -1,0 +1,61 @@
+"""pytest configuration: the `gpu` marker and shared helpers.
+
+`-m "not gpu"` runs everywhere (oracle vs golden vectors, host logic, C-ABI symbol
+checks, gloo multi-process path).  `-m gpu` tests call the HIP path through the
+C-ABI and are the parity tests proper.
+"""
+import importlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
+GOLDEN = os.path.join(TESTS, "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_cases():
+    with open(os.path.join(GOLDEN, "reads_counter_cases.json")) as f:
+        return json.load(f)["cases"]
+
+
+def case_fastq(case):
+    """bytes of the FASTQ input of a golden case (inline, or regenerated from tests/synth.py)"""
+    import synth
+    if case.get("synth"):
+        s = case["synth"]
+        guides = synth.make_library(s["n_guides"], s["glen"], s["lib_seed"])
+        return synth.make_fastq(synth.Spec(**s["spec"]), guides)
+    return case["fastq"].encode("latin-1")
+
+
+def loader_view(features):
+    """What features_loader (fast2q.py:148-166) keeps of [[name, seq-as-written]...]:
+    upper-cased, blanks removed, first occurrence of a sequence wins."""
+    out, seen = [], set()
+    for name, seq in features:
+        s = seq.upper().replace(" ", "")
+        if s not in seen:
+            seen.add(s)
+            out.append((name, s))
+    return out
+
+
+def pkg():
+    """the product package (its directory name starts with a digit, so importlib)"""
+    return importlib.import_module("2fast2q_amd")
+
+
+@pytest.fixture(scope="session")
+def cases():
+    return load_cases()
