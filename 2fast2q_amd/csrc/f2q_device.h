@@ -1,0 +1,561 @@
+// f2q_device.h -- per-read logic of the counting path, written once as host/device inline
+// functions.  The HIP kernels (f2q_kernels.hip) call these per lane; tests/emu compiles the same
+// functions with g++ to unit-test the lane logic on a machine without a GPU (test infrastructure
+// only -- the product never executes them on the host).
+//
+// Reference semantics restated here (fast2q/fast2q.py): window extraction :349-355, Phred rule
+// :1112-1129/:357, anchored search :215-285 + :628-658, exact hit :365-367, unique-nearest
+// mismatch search :692-750 + :660-690, counters :310-316/:366-393, EC dict :382-387.
+#pragma once
+#include <stdint.h>
+
+#ifndef F2Q_HD
+#ifdef __HIPCC__
+#define F2Q_HD __host__ __device__ __forceinline__
+#else
+#define F2Q_HD inline
+#endif
+#endif
+
+#define F2Q_DEV_MAX_ITER 16
+#define F2Q_ANCHOR_MAX 128
+#define F2Q_MAX_PIECES 8
+#define F2Q_REG_MAXLEN 31          // longest feature/window handled as a 2-bit u64 key
+#define F2Q_TILE 256               // reads per packed tile (= threads per workgroup)
+#define F2Q_LEN_SKIP 0xFFFFu       // len-plane marker: slot handled by the general path
+
+namespace f2q {
+
+static const uint64_t KEY_EMPTY = ~0ull;
+
+// ---------------------------------------------------------------------------------------------
+// run parameters (device copy of f2q_params after set-up)
+// ---------------------------------------------------------------------------------------------
+struct RunDev {
+    int32_t mode, miss, length, fixed, n_iter;
+    int32_t thr, thr_up, thr_down;     // a quality byte c fails iff 33 <= c <= thr  (thr < 33: never)
+    int32_t msu, msd, has_up, has_down;
+    int32_t start[F2Q_DEV_MAX_ITER];
+    int32_t up_len[F2Q_DEV_MAX_ITER], down_len[F2Q_DEV_MAX_ITER];
+    uint8_t up[F2Q_DEV_MAX_ITER][F2Q_ANCHOR_MAX];
+    uint8_t down[F2Q_DEV_MAX_ITER][F2Q_ANCHOR_MAX];
+};
+
+// ---------------------------------------------------------------------------------------------
+// library index
+// ---------------------------------------------------------------------------------------------
+struct PieceDesc { uint32_t off, bits, shift, pad; uint64_t mask; };   // table = 1<<bits slots at tab[off]
+struct LenGroup { uint32_t n, n_pieces; PieceDesc exact; PieceDesc piece[F2Q_MAX_PIECES]; };
+
+struct LibDev {
+    uint32_t n_features, n_irregular;
+    const uint64_t *tab_keys;          // open-addressing slots: 2-bit feature key or KEY_EMPTY
+    const uint32_t *tab_idx;           // feature index of the slot
+    const uint8_t *feat_bytes;         // all features, raw (upper-case) bytes
+    const uint32_t *feat_off;          // n_features + 1
+    const uint32_t *irr_ids;           // features that are not ACGT-only / longer than 31
+    LenGroup grp[F2Q_REG_MAXLEN + 1];  // by feature length
+};
+
+// ---------------------------------------------------------------------------------------------
+// accumulators
+// ---------------------------------------------------------------------------------------------
+struct Accum {
+    unsigned long long *counts;        // [n_features]
+    unsigned long long *stats;         // [5]
+};
+
+struct EcDev {
+    unsigned long long *slots;         // 0 empty | (fp<<32)|0xFFFFFFFF locked | (fp<<32)|(entry+1)
+    uint32_t mask;                     // slots - 1
+    uint32_t max_entries;
+    unsigned long long *ent_off;       // arena offset of the key (in 4-byte words)
+    uint32_t *ent_len;                 // key length in bytes
+    unsigned long long *ent_count;
+    unsigned long long *ent_first;     // min global read index that produced the key
+    uint32_t *arena;                   // key bytes, 4 per word, little endian
+    unsigned long long arena_words;
+    unsigned long long *ctr;           // [0] n_entries  [1] arena words used  [2] overflow flag
+};
+
+F2Q_HD void acc_add(unsigned long long *p, unsigned long long v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(p, v);
+#else
+    *p += v;
+#endif
+}
+
+F2Q_HD uint32_t hash_slot(uint64_t k, uint32_t bits)
+{
+    return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - bits));
+}
+
+F2Q_HD uint8_t up8(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+F2Q_HD bool q_fails(uint8_t c, int thr) { return c >= 33 && (int)c <= thr; }
+
+// Python slice bounds x[a:b] for len n
+F2Q_HD void py_slice(int n, int a, int b, int &oa, int &ob)
+{
+    if (a < 0) { a += n; if (a < 0) a = 0; } else if (a > n) a = n;
+    if (b < 0) { b += n; if (b < 0) b = 0; } else if (b > n) b = n;
+    if (b < a) b = a;
+    oa = a; ob = b;
+}
+
+// 2-bit code of an upper-case base, 4 = not ACGT
+F2Q_HD uint32_t base_code(uint8_t c)
+{
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+F2Q_HD int popc64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+// number of differing bases between two 2-bit keys (unused high bits equal in both)
+F2Q_HD int ham2(uint64_t x)
+{
+    return popc64((x | (x >> 1)) & 0x5555555555555555ull);
+}
+
+// running unique-nearest state: best distance seen so far (starts at miss), how many features sit
+// at it, and one of them.  Equivalent to the reference's iterative deepening (:734-750): assign
+// iff the minimum distance d* <= miss is attained by exactly one feature.
+struct MinTrack {
+    int best, cnt; uint32_t idx;
+    F2Q_HD void init(int miss) { best = miss; cnt = 0; idx = 0; }
+    F2Q_HD void offer(int d, uint32_t i)
+    {
+        if (d < best) { best = d; cnt = 1; idx = i; }
+        else if (d == best) { cnt++; idx = i; }
+    }
+};
+
+// exact probe of the 2-bit table: feature index or -1
+F2Q_HD int lib_exact(const LibDev &lib, uint64_t key, int L)
+{
+    const LenGroup &g = lib.grp[L];
+    if (g.n == 0) return -1;
+    const uint32_t m = (1u << g.exact.bits) - 1u;
+    uint32_t s = hash_slot(key, g.exact.bits);
+    for (;;) {
+        uint64_t k = lib.tab_keys[g.exact.off + s];
+        if (k == key) return (int)lib.tab_idx[g.exact.off + s];
+        if (k == KEY_EMPTY) return -1;
+        s = (s + 1) & m;
+    }
+}
+
+// pigeonhole search over the regular features of length L: every feature within `miss` of the
+// query agrees with it exactly on at least one of the miss+1 pieces, so only the features
+// sharing a piece value are verified (XOR + popcount).  A feature seen through several pieces
+// is counted at the first one.  `forced` = positions of the query that mismatch everything
+// (bit 2j set for base j), used for windows holding a non-ACGT symbol.
+F2Q_HD void lib_near(const LibDev &lib, uint64_t key, int L, uint64_t forced, MinTrack &t)
+{
+    const LenGroup &g = lib.grp[L];
+    if (g.n == 0) return;
+    const int nforced = popc64(forced);
+    for (uint32_t p = 0; p < g.n_pieces; p++) {
+        const PieceDesc pd = g.piece[p];
+        if ((forced >> pd.shift) & pd.mask & 0x5555555555555555ull) continue;   // piece can never agree
+        const uint64_t pv = (key >> pd.shift) & pd.mask;
+        const uint32_t m = (1u << pd.bits) - 1u;
+        uint32_t s = hash_slot(pv, pd.bits);
+        for (;;) {
+            uint64_t k = lib.tab_keys[pd.off + s];
+            if (k == KEY_EMPTY) break;
+            uint64_t x = k ^ key;
+            if (((x >> pd.shift) & pd.mask) == 0) {
+                bool dup = false;
+                for (uint32_t q = 0; q < p; q++) {
+                    const PieceDesc qd = g.piece[q];
+                    if ((forced >> qd.shift) & qd.mask & 0x5555555555555555ull) continue;
+                    if (((x >> qd.shift) & qd.mask) == 0) { dup = true; break; }
+                }
+                if (!dup) {
+                    uint64_t xm = x & ~(forced | (forced << 1));
+                    t.offer(ham2(xm) + nforced, lib.tab_idx[pd.off + s]);
+                }
+            }
+            s = (s + 1) & m;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// general path: keys as byte strings (any symbols, any length, ':'-joined multi-window keys)
+// ---------------------------------------------------------------------------------------------
+struct KeyView {
+    const uint8_t *seq;                 // the read's sequence line (raw case)
+    int nseg; int a[F2Q_DEV_MAX_ITER], b[F2Q_DEV_MAX_ITER];
+    int len;                            // total key length incl. ':' separators
+    F2Q_HD uint8_t at(int k) const
+    {
+        for (int s = 0; s < nseg; s++) {
+            int n = b[s] - a[s];
+            if (k < n) return up8(seq[a[s] + k]);
+            k -= n;
+            if (s + 1 < nseg) { if (k == 0) return (uint8_t)':'; k--; }
+        }
+        return 0;
+    }
+};
+
+// distance between the key and feature f (same length), giving up once it exceeds `limit`
+F2Q_HD int key_dist(const KeyView &kv, const uint8_t *fb, int limit)
+{
+    int d = 0, k = 0;
+    for (int s = 0; s < kv.nseg; s++) {
+        for (int j = kv.a[s]; j < kv.b[s]; j++, k++) {
+            if (up8(kv.seq[j]) != fb[k]) { if (++d > limit) return d; }
+        }
+        if (s + 1 < kv.nseg) { if (fb[k] != (uint8_t)':') { if (++d > limit) return d; } k++; }
+    }
+    return d;
+}
+
+// brute force over a list of features (ids == nullptr: all features)
+F2Q_HD void lib_scan(const LibDev &lib, const KeyView &kv, const uint32_t *ids, uint32_t n, MinTrack &t)
+{
+    for (uint32_t e = 0; e < n; e++) {
+        uint32_t f = ids ? ids[e] : e;
+        uint32_t o = lib.feat_off[f];
+        if ((int)(lib.feat_off[f + 1] - o) != kv.len) continue;          // only same-length features (:683)
+        int d = key_dist(kv, lib.feat_bytes + o, t.best);
+        if (d <= t.best) t.offer(d, f);
+    }
+}
+
+// Counter-mode decision for one extracted key: returns 1 perfect, 2 imperfect, 3 non-aligned,
+// and the feature index in `idx`.
+F2Q_HD int match_key(const RunDev &run, const LibDev &lib, const KeyView &kv, uint32_t &idx)
+{
+    // is the key a plain ACGT string short enough for the 2-bit index?
+    bool regular = (kv.nseg == 1 && kv.len >= 1 && kv.len <= F2Q_REG_MAXLEN);
+    uint64_t key = 0, forced = 0;
+    int nforced = 0;
+    if (regular) {
+        for (int j = 0; j < kv.len; j++) {
+            uint32_t c = base_code(up8(kv.seq[kv.a[0] + j]));
+            if (c > 3u) { forced |= 1ull << (2 * j); nforced++; c = 0; }
+            key |= (uint64_t)c << (2 * j);
+        }
+    }
+    MinTrack t; t.init(run.miss);
+    if (regular) {
+        if (nforced == 0) {
+            int e = lib_exact(lib, key, kv.len);
+            if (e >= 0) { idx = (uint32_t)e; return 1; }
+        }
+        // regular features: a non-ACGT query symbol mismatches every one of them
+        if (run.miss > 0 && nforced <= run.miss) lib_near(lib, key, kv.len, forced, t);
+        // irregular features (non-ACGT symbols, or longer than 31) are compared byte-wise
+        if (lib.n_irregular && (run.miss > 0 || nforced > 0)) lib_scan(lib, kv, lib.irr_ids, lib.n_irregular, t);
+    } else {
+        lib_scan(lib, kv, nullptr, lib.n_features, t);
+    }
+    if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? 1 : 2; }
+    // best == 0 with cnt > 1 cannot happen (library sequences are unique)
+    return 3;
+}
+
+// Phred test of quality bytes [a,b) against threshold thr
+F2Q_HD bool qual_range_fails(const uint8_t *q, int a, int b, int thr)
+{
+    if (thr < 33) return false;
+    for (int i = a; i < b; i++) if (q_fails(q[i], thr)) return true;
+    return false;
+}
+
+// border_finder (:628-658) on raw bytes: first p in [from, r-s] within k mismatches, else -1
+F2Q_HD int border_find(const uint8_t *anchor, int s, const uint8_t *read, int r, int k, int from)
+{
+    if (from < 0) from = 0;
+    for (int p = from; p + s <= r && p < r; p++) {
+        int d = 0;
+        for (int j = 0; j < s; j++) { if (anchor[j] != read[p + j]) { if (++d > k) break; } }
+        if (d <= k) return p;
+    }
+    return -1;
+}
+
+// sequence_tinder (:215-285): true + (start,end) or false
+F2Q_HD bool tinder(const RunDev &run, const uint8_t *seq, int r, const uint8_t *qual, int qn, int i,
+                   int &start, int &end)
+{
+    int a, b;
+    if (run.has_up && run.has_down) {
+        int st = border_find(run.up[i], run.up_len[i], seq, r, run.msu, 0);
+        if (st < 0) return false;
+        int en = border_find(run.down[i], run.down_len[i], seq, r, run.msd, st + run.up_len[i]);
+        if (en < 0) return false;
+        py_slice(qn, st, st + run.up_len[i], a, b);
+        if (qual_range_fails(qual, a, b, run.thr_up)) return false;
+        py_slice(qn, en, en + run.down_len[i], a, b);
+        if (qual_range_fails(qual, a, b, run.thr_down)) return false;
+        start = st + run.up_len[i]; end = en;
+        return true;
+    } else if (run.has_up) {
+        int st = border_find(run.up[i], run.up_len[i], seq, r, run.msu, 0);
+        if (st < 0) return false;
+        py_slice(qn, st, st + run.up_len[i], a, b);
+        if (qual_range_fails(qual, a, b, run.thr_up)) return false;
+        start = st + run.up_len[i]; end = start + run.length;
+        return true;
+    } else if (run.has_down) {
+        int en = border_find(run.down[i], run.down_len[i], seq, r, run.msd, 0);
+        if (en < 0) return false;
+        py_slice(qn, en, en + run.down_len[i], a, b);
+        if (qual_range_fails(qual, a, b, run.thr_down)) return false;
+        start = en - run.length; end = en;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EC byte-string table (device side of the de-novo dict, :382-387)
+// ---------------------------------------------------------------------------------------------
+F2Q_HD uint64_t key_hash(const KeyView &kv)
+{
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)kv.len;
+    for (int k = 0; k < kv.len; k++) { h ^= kv.at(k); h *= 1099511628211ull; }
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define F2Q_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F2Q_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F2Q_ST64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F2Q_ST32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define F2Q_LD64(p) (*(p))
+#define F2Q_LD32(p) (*(p))
+#define F2Q_ST64(p, v) (*(p) = (v))
+#define F2Q_ST32(p, v) (*(p) = (v))
+#endif
+
+F2Q_HD unsigned long long ec_cas(unsigned long long *p, unsigned long long cmp, unsigned long long val)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicCAS(p, cmp, val);
+#else
+    unsigned long long old = *p; if (old == cmp) *p = val; return old;
+#endif
+}
+F2Q_HD unsigned long long ec_fetch_add(unsigned long long *p, unsigned long long v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    unsigned long long old = *p; *p += v; return old;
+#endif
+}
+F2Q_HD void ec_min(unsigned long long *p, unsigned long long v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+
+F2Q_HD uint32_t key_word(const KeyView &kv, int w)
+{
+    uint32_t v = 0;
+    for (int j = 0; j < 4; j++) { int k = 4 * w + j; if (k < kv.len) v |= (uint32_t)kv.at(k) << (8 * j); }
+    return v;
+}
+
+// Insert-or-increment.  All table words are read and written with agent-scope atomics (sc1), so
+// the table is coherent across XCDs inside one launch.  A slot is claimed with one CAS (locked),
+// filled, then published; lanes that meet a locked slot of the same fingerprint re-poll it.  The
+// claimer never waits on anybody, so the loop cannot deadlock inside a wave; polls are bounded.
+F2Q_HD void ec_insert(const EcDev &ec, const KeyView &kv, unsigned long long read_index)
+{
+    const uint64_t h = key_hash(kv);
+    const unsigned long long fp = (h >> 32) & 0xFFFFFFFFull;
+    const unsigned long long locked = (fp << 32) | 0xFFFFFFFFull;
+    const int nw = (kv.len + 3) >> 2;
+    uint32_t s = (uint32_t)h & ec.mask;
+    for (uint32_t guard = 0; guard < (1u << 22); guard++) {
+        unsigned long long v = F2Q_LD64(&ec.slots[s]);
+        if (v == 0ull) {
+            unsigned long long old = ec_cas(&ec.slots[s], 0ull, locked);
+            if (old == 0ull) {
+                unsigned long long e = ec_fetch_add(&ec.ctr[0], 1ull);
+                unsigned long long off = ec_fetch_add(&ec.ctr[1], (unsigned long long)nw);
+                if (e >= ec.max_entries || off + (unsigned long long)nw > ec.arena_words) {
+                    F2Q_ST64(&ec.ctr[2], 1ull);          // overflow: the host grows the table and re-runs
+                    return;                              // (slot stays locked; the table is discarded)
+                }
+                for (int w = 0; w < nw; w++) F2Q_ST32(&ec.arena[off + w], key_word(kv, w));
+                F2Q_ST64(&ec.ent_off[e], off);
+                F2Q_ST32(&ec.ent_len[e], (uint32_t)kv.len);
+                ec_fetch_add(&ec.ent_count[e], 1ull);
+                ec_min(&ec.ent_first[e], read_index);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __threadfence();                         // entry + key bytes before the publish
+#endif
+                F2Q_ST64(&ec.slots[s], (fp << 32) | (e + 1ull));
+                return;
+            }
+            v = old;
+        }
+        if ((v >> 32) == fp) {
+            if ((v & 0xFFFFFFFFull) == 0xFFFFFFFFull) {                       // being filled: poll again
+                if ((guard & 1023u) == 1023u && F2Q_LD64(&ec.ctr[2]) != 0ull) return;   // table overflowed
+                continue;
+            }
+            unsigned long long e = (v & 0xFFFFFFFFull) - 1ull;
+            if (F2Q_LD32(&ec.ent_len[e]) == (uint32_t)kv.len) {
+                unsigned long long off = F2Q_LD64(&ec.ent_off[e]);
+                bool same = true;
+                for (int w = 0; w < nw && same; w++) same = (F2Q_LD32(&ec.arena[off + w]) == key_word(kv, w));
+                if (same) {
+                    ec_fetch_add(&ec.ent_count[e], 1ull);
+                    ec_min(&ec.ent_first[e], read_index);
+                    return;
+                }
+            }
+        }
+        s = (s + 1) & ec.mask;
+    }
+    F2Q_ST64(&ec.ctr[2], 2ull);                         // probe bound hit: reported as an error
+}
+
+// ---------------------------------------------------------------------------------------------
+// general path: one read given as raw bytes.  st[] = the 5 reference counters (thread-local).
+// ---------------------------------------------------------------------------------------------
+F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, const Accum &acc,
+                         const uint8_t *seq, int r, const uint8_t *qual, int qn,
+                         unsigned long long read_index, unsigned long long st[5])
+{
+    KeyView kv; kv.seq = seq; kv.nseg = 0; kv.len = 0;
+    bool all_failed = true;
+    for (int i = 0; i < run.n_iter; i++) {
+        int start, end;
+        if (run.fixed) { start = run.start[i]; end = run.start[i] + run.length; }
+        else {
+            if (!tinder(run, seq, r, qual, qn, i, start, end)) continue;
+            if (end < start) continue;                                           // :343-345
+        }
+        int a, b, qa, qb;
+        py_slice(r, start, end, a, b);                                           // :354
+        py_slice(qn, start, end, qa, qb);                                        // :355
+        if (qual_range_fails(qual, qa, qb, run.thr)) continue;                   // :357-360
+        all_failed = false;
+        kv.a[kv.nseg] = a; kv.b[kv.nseg] = b; kv.nseg++;
+        kv.len += (b - a) + (kv.nseg > 1 ? 1 : 0);
+    }
+    if (kv.nseg > 0) {
+        if (run.mode == 0) {
+            uint32_t idx = 0;
+            int res = match_key(run, lib, kv, idx);
+            if (res == 1 || res == 2) acc_add(&acc.counts[idx], 1ull);
+            st[res]++;
+        } else {
+            ec_insert(ec, kv, read_index);
+            st[1]++;                                                             // :387
+        }
+    }
+    if (all_failed) st[4]++;                                                     // :389-390
+    st[0]++;                                                                     // :393
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast path, fixed offset: one lane = one read of a packed tile.
+// tile planes are [word][lane]: bases 16 per u32 (2 bits, LSB first), qualities 4 per u32.
+// ---------------------------------------------------------------------------------------------
+struct PackedBlock {
+    uint64_t n_slots;          // read slots (multiple of F2Q_TILE; slots >= n_valid hold len = SKIP)
+    uint64_t first_index;      // global index of slot 0 (for EC first-occurrence ordering)
+    uint32_t n_tiles, wb, wq, rmax;
+    const uint32_t *bases;     // [n_tiles][wb][F2Q_TILE]
+    const uint32_t *qual;      // [n_tiles][wq][F2Q_TILE]
+    const uint16_t *len;       // [n_tiles][F2Q_TILE] or nullptr (all reads rmax long, none skipped)
+};
+
+// any byte of the 4 in w (all < 128) inside [33, thr]?  mask selects the bytes to test (0x80 per byte)
+F2Q_HD uint32_t qfail4(uint32_t w, uint32_t add_lo, uint32_t add_hi, uint32_t mask)
+{
+    // byte >= 33  <=>  bit7 of (byte + 95);   byte > thr  <=>  bit7 of (byte + 127 - thr)
+    return (w + add_lo) & ~(w + add_hi) & mask;
+}
+
+// returns the reference counter to bump (1 perfect, 2 imperfect, 3 non-aligned, 4 quality failed,
+// 0 = slot skipped) and the feature index.  Needs: fixed mode, one window, length <= 31, start >= 0.
+F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &pb, uint32_t tile,
+                      uint32_t lane, uint32_t &idx)
+{
+    int rlen = (int)pb.rmax;
+    if (pb.len) {
+        uint32_t l = pb.len[(uint64_t)tile * F2Q_TILE + lane];
+        if (l == F2Q_LEN_SKIP) return 0;
+        rlen = (int)l;
+    }
+    const int st = run.start[0];
+    int a = st < rlen ? st : rlen;
+    int b = (st + run.length) < rlen ? (st + run.length) : rlen;
+    const int L = b - a;                                     // clipped window (Python slice, :354)
+    // ---- Phred mask over quality bytes [a,b) ----
+    if (run.thr >= 33 && L > 0) {
+        const uint32_t add_lo = 0x5F5F5F5Fu;                                   // +95
+        const uint32_t add_hi = (uint32_t)(127 - run.thr) * 0x01010101u;
+        const uint32_t *qp = pb.qual + ((uint64_t)tile * pb.wq) * F2Q_TILE + lane;
+        uint32_t bad = 0;
+        const int w0 = a >> 2, w1 = (b - 1) >> 2;
+        for (int w = w0; w <= w1; w++) {
+            uint32_t m = 0x80808080u;
+            if (w == w0) m &= 0xFFFFFFFFu << (8 * (a & 3));
+            if (w == w1) m &= 0xFFFFFFFFu >> (8 * (3 - ((b - 1) & 3)));
+            bad |= qfail4(qp[(uint64_t)w * F2Q_TILE], add_lo, add_hi, m);
+        }
+        if (bad) return 4;
+    }
+    // ---- 2-bit key of bases [a,b) ----
+    uint64_t key = 0;
+    if (L > 0) {
+        const uint32_t *bp = pb.bases + ((uint64_t)tile * pb.wb) * F2Q_TILE + lane;
+        const int w0 = a >> 4, w1 = (b - 1) >> 4;              // at most 3 words for L <= 31
+        uint64_t lo = bp[(uint64_t)w0 * F2Q_TILE];
+        uint64_t mid = (w1 > w0) ? bp[(uint64_t)(w0 + 1) * F2Q_TILE] : 0u;
+        uint64_t hi = (w1 > w0 + 1) ? bp[(uint64_t)(w0 + 2) * F2Q_TILE] : 0u;
+        const int sh = 2 * (a & 15);
+        key = (lo | (mid << 32)) >> sh;
+        if (sh) key |= hi << (64 - sh);
+        key &= (L >= 32) ? ~0ull : ((1ull << (2 * L)) - 1ull);
+    }
+    if (L < 1) {
+        // empty window: the key "" can only match an (irregular) empty feature
+        KeyView kv; kv.seq = nullptr; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = 0; kv.len = 0;
+        MinTrack t; t.init(run.miss);
+        if (lib.n_irregular) lib_scan(lib, kv, lib.irr_ids, lib.n_irregular, t);
+        if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? 1 : 2; }
+        return 3;
+    }
+    int e = lib_exact(lib, key, L);
+    if (e >= 0) { idx = (uint32_t)e; return 1; }
+    if (run.miss == 0 && lib.n_irregular == 0) return 3;
+    MinTrack t; t.init(run.miss);
+    if (run.miss > 0) lib_near(lib, key, L, 0ull, t);
+    if (lib.n_irregular) {
+        // decode the window for the byte-wise scan of irregular features
+        uint8_t wbuf[F2Q_REG_MAXLEN + 1];
+        for (int j = 0; j < L; j++) wbuf[j] = (uint8_t)"ACGT"[(key >> (2 * j)) & 3];
+        KeyView kv; kv.seq = wbuf; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = L; kv.len = L;
+        lib_scan(lib, kv, lib.irr_ids, lib.n_irregular, t);
+    }
+    if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? 1 : 2; }
+    return 3;
+}
+
+} // namespace f2q

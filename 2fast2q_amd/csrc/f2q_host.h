@@ -1,0 +1,288 @@
+// f2q_host.h -- host-side helpers of libf2q_hip.so: library index construction and FASTQ
+// framing / read classification / tile packing.  Plain C++ (no HIP calls) so the same code is
+// unit-tested on a GPU-less machine through tests/emu.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/f2q.h"
+#include "f2q_device.h"
+
+namespace f2q {
+
+// ---------------------------------------------------------------------------------------------
+// library index (replaces binary_converter, fast2q.py:188-213)
+// ---------------------------------------------------------------------------------------------
+struct HostIndex {
+    std::vector<uint64_t> tab_keys;
+    std::vector<uint32_t> tab_idx;
+    std::vector<uint8_t> feat_bytes;
+    std::vector<uint32_t> feat_off;
+    std::vector<uint32_t> irr_ids;
+    std::vector<uint64_t> key2;          // 2-bit key per feature (0 for irregular ones)
+    LenGroup grp[F2Q_REG_MAXLEN + 1];
+    uint32_t n_features = 0, n_irregular = 0;
+};
+
+inline bool feature_key(const uint8_t *s, uint32_t n, uint64_t &key)
+{
+    if (n < 1 || n > F2Q_REG_MAXLEN) return false;
+    key = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        uint32_t c = base_code(s[j]);
+        if (c > 3u) return false;
+        key |= (uint64_t)c << (2 * j);
+    }
+    return true;
+}
+
+inline uint32_t table_bits(uint32_t n)
+{
+    uint32_t bits = 4;
+    while ((1ull << bits) < 2ull * n) bits++;
+    return bits;
+}
+
+inline void table_insert(std::vector<uint64_t> &keys, std::vector<uint32_t> &idx, const PieceDesc &pd,
+                         uint64_t hashed, uint64_t full_key, uint32_t id)
+{
+    uint32_t m = (1u << pd.bits) - 1u, s = hash_slot(hashed, pd.bits);
+    while (keys[pd.off + s] != KEY_EMPTY) s = (s + 1) & m;
+    keys[pd.off + s] = full_key; idx[pd.off + s] = id;
+}
+
+inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss)
+{
+    ix = HostIndex();
+    ix.n_features = n;
+    ix.feat_off.assign(offs, offs + n + 1);
+    uint32_t base = offs[0];
+    for (auto &o : ix.feat_off) o -= base;
+    ix.feat_bytes.assign((const uint8_t *)seqs + base, (const uint8_t *)seqs + offs[n]);
+    ix.feat_bytes.resize(ix.feat_bytes.size() + 8, 0);
+    ix.key2.assign(n, 0);
+    memset(ix.grp, 0, sizeof ix.grp);
+    std::vector<std::vector<uint32_t>> by_len(F2Q_REG_MAXLEN + 1);
+    for (uint32_t f = 0; f < n; f++) {
+        uint32_t len = ix.feat_off[f + 1] - ix.feat_off[f];
+        uint64_t k;
+        if (feature_key(ix.feat_bytes.data() + ix.feat_off[f], len, k)) { ix.key2[f] = k; by_len[len].push_back(f); }
+        else ix.irr_ids.push_back(f);
+    }
+    uint32_t off = 0;
+    for (int L = 1; L <= F2Q_REG_MAXLEN; L++) {
+        LenGroup &g = ix.grp[L];
+        g.n = (uint32_t)by_len[L].size();
+        if (!g.n) continue;
+        const uint32_t bits = table_bits(g.n);
+        g.exact.off = off; g.exact.bits = bits; g.exact.shift = 0; g.exact.mask = ~0ull;
+        off += 1u << bits;
+        // pigeonhole pieces: miss+1 contiguous base ranges; when that many do not fit (or exceed the
+        // descriptor), one zero-width piece puts every feature in one chain (exhaustive scan)
+        int P = miss > 0 ? miss + 1 : 0;
+        if (P > L || P > F2Q_MAX_PIECES) P = 1, g.n_pieces = 1;
+        else g.n_pieces = (uint32_t)P;
+        for (uint32_t p = 0; p < g.n_pieces; p++) {
+            PieceDesc &pd = g.piece[p];
+            pd.off = off; pd.bits = bits; off += 1u << bits;
+            if (miss + 1 > L || miss + 1 > F2Q_MAX_PIECES) { pd.shift = 0; pd.mask = 0; }
+            else {
+                int b0 = (int)((long)p * L / P), b1 = (int)((long)(p + 1) * L / P);
+                pd.shift = (uint32_t)(2 * b0);
+                pd.mask = (b1 - b0 >= 32) ? ~0ull : ((1ull << (2 * (b1 - b0))) - 1ull);
+            }
+        }
+    }
+    ix.tab_keys.assign(off ? off : 1, KEY_EMPTY);
+    ix.tab_idx.assign(off ? off : 1, 0);
+    for (int L = 1; L <= F2Q_REG_MAXLEN; L++) {
+        LenGroup &g = ix.grp[L];
+        for (uint32_t f : by_len[L]) {
+            uint64_t k = ix.key2[f];
+            table_insert(ix.tab_keys, ix.tab_idx, g.exact, k, k, f);
+            for (uint32_t p = 0; p < g.n_pieces; p++)
+                table_insert(ix.tab_keys, ix.tab_idx, g.piece[p], (k >> g.piece[p].shift) & g.piece[p].mask, k, f);
+        }
+    }
+    ix.n_irregular = (uint32_t)ix.irr_ids.size();
+    if (ix.irr_ids.empty()) ix.irr_ids.push_back(0);     // keep the device array non-empty
+}
+
+// ---------------------------------------------------------------------------------------------
+// FASTQ framing (fastq_parser :324-328): '\n'-separated lines, rstrip(), 4 lines per record
+// ---------------------------------------------------------------------------------------------
+struct Rec { const uint8_t *seq; const uint8_t *qual; uint32_t len, qlen; };
+
+inline uint32_t rstrip_len(const uint8_t *p, size_t n)
+{
+    while (n > 0) {
+        uint8_t c = p[n - 1];
+        if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c) n--; else break;
+    }
+    return (uint32_t)n;
+}
+
+// frames complete records of buf; returns bytes consumed up to the end of the last complete record
+inline size_t frame_fastq(const uint8_t *buf, size_t nbytes, std::vector<Rec> &out)
+{
+    size_t pos = 0, consumed = 0;
+    const uint8_t *ln[4]; uint32_t ll[4]; int k = 0;
+    while (pos < nbytes) {
+        const uint8_t *nl = (const uint8_t *)memchr(buf + pos, '\n', nbytes - pos);
+        size_t eol = nl ? (size_t)(nl - buf) : nbytes;
+        ln[k] = buf + pos; ll[k] = rstrip_len(buf + pos, eol - pos); k++;
+        pos = nl ? eol + 1 : nbytes;
+        if (k == 4) { out.push_back(Rec{ln[1], ln[3], ll[1], ll[3]}); k = 0; consumed = pos; }
+    }
+    return consumed;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing plan
+// ---------------------------------------------------------------------------------------------
+#define F2Q_PACK_MAXLEN 512
+
+struct PackPlan {
+    bool fast_fixed = false;       // fixed offset, one window, 0 <= length <= 31, Counter mode
+    int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
+    int from = 0;                  // ... and only [from, need) is ever looked at
+};
+
+inline PackPlan make_plan(const RunDev &run)
+{
+    PackPlan pl;
+    pl.fast_fixed = run.mode == 0 && run.fixed && run.n_iter == 1 && run.start[0] >= 0 && run.length >= 0 &&
+                    run.length <= F2Q_REG_MAXLEN && run.start[0] + run.length <= F2Q_PACK_MAXLEN;
+    pl.need = pl.fast_fixed ? run.start[0] + run.length : 0;
+    pl.from = pl.fast_fixed ? run.start[0] : 0;
+    return pl;
+}
+
+// Can this read go through the packed fast path?  The 2-bit planes cannot carry lower case,
+// N/IUPAC symbols, a quality line of another length or quality bytes >= 128 (the Phred SWAR test
+// relies on 7-bit bytes); such reads take the general path, which works on the raw bytes.
+inline bool read_is_clean(const PackPlan &pl, const Rec &r)
+{
+    if (!pl.fast_fixed) return false;
+    if (r.qlen != r.len) return false;
+    uint32_t b = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
+    for (uint32_t j = (uint32_t)pl.from; j < b; j++) {
+        if (base_code(r.seq[j]) > 3u) return false;
+        if (r.qual[j] & 0x80) return false;
+    }
+    return true;
+}
+
+struct HostPacked {
+    uint32_t n_tiles = 0, wb = 0, wq = 0, rmax = 0;
+    uint64_t n_clean = 0;
+    std::vector<uint32_t> bases, qual;
+    std::vector<uint16_t> len;
+    // general-path records (raw bytes)
+    std::vector<uint8_t> raw;                  // seq bytes then qual bytes per record
+    std::vector<unsigned long long> g_off;     // per record: offset of seq in raw (qual follows at +len)
+    std::vector<uint32_t> g_len, g_qlen, g_index;
+};
+
+inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostPacked &hp)
+{
+    hp = HostPacked();
+    std::vector<uint32_t> clean; clean.reserve(recs.size());
+    uint32_t rmax = 0;
+    for (uint32_t i = 0; i < recs.size(); i++) {
+        const Rec &r = recs[i];
+        if (read_is_clean(pl, r)) {
+            clean.push_back(i);
+            uint32_t l = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
+            if (l > rmax) rmax = l;
+        } else {
+            hp.g_off.push_back(hp.raw.size());
+            hp.g_len.push_back(r.len); hp.g_qlen.push_back(r.qlen); hp.g_index.push_back(i);
+            hp.raw.insert(hp.raw.end(), r.seq, r.seq + r.len);
+            hp.raw.insert(hp.raw.end(), r.qual, r.qual + r.qlen);
+        }
+    }
+    hp.raw.resize(hp.raw.size() + 8, 0);
+    hp.n_clean = clean.size();
+    if (clean.empty()) return;
+    if (rmax == 0) rmax = 1;
+    hp.rmax = rmax; hp.wb = (rmax + 15) / 16; hp.wq = (rmax + 3) / 4;
+    hp.n_tiles = (uint32_t)((clean.size() + F2Q_TILE - 1) / F2Q_TILE);
+    hp.bases.assign((size_t)hp.n_tiles * hp.wb * F2Q_TILE, 0);
+    hp.qual.assign((size_t)hp.n_tiles * hp.wq * F2Q_TILE, 0);
+    hp.len.assign((size_t)hp.n_tiles * F2Q_TILE, (uint16_t)F2Q_LEN_SKIP);
+    for (size_t s = 0; s < clean.size(); s++) {
+        const Rec &r = recs[clean[s]];
+        const size_t tile = s / F2Q_TILE, lane = s % F2Q_TILE;
+        const uint32_t l = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
+        hp.len[tile * F2Q_TILE + lane] = (uint16_t)l;
+        uint32_t *bp = hp.bases.data() + tile * hp.wb * F2Q_TILE + lane;
+        uint32_t *qp = hp.qual.data() + tile * hp.wq * F2Q_TILE + lane;
+        for (uint32_t w = 0; w * 16 < l; w++) {
+            uint32_t v = 0;
+            for (uint32_t j = 0; j < 16 && w * 16 + j < l; j++) {
+                uint32_t c = base_code(r.seq[w * 16 + j]);          // outside the window anything may occur:
+                v |= (c > 3u ? 0u : c) << (2 * j);                  // it is never looked at, store 'A'
+            }
+            bp[(size_t)w * F2Q_TILE] = v;
+        }
+        for (uint32_t w = 0; w * 4 < l; w++) {
+            uint32_t v = 0;
+            for (uint32_t j = 0; j < 4 && w * 4 + j < l; j++) {
+                uint32_t q = r.qual[w * 4 + j];
+                v |= (q & 0x80u ? 0u : q) << (8 * j);               // keep every stored byte 7-bit (SWAR)
+            }
+            qp[(size_t)w * F2Q_TILE] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// run set-up (reads_counter :536-558, initializer :1112-1129)
+// ---------------------------------------------------------------------------------------------
+inline int phred_threshold(int ph)
+{
+    if (ph <= 0) ph = 1;                       // :1118-1125
+    int thr = ph + 31;                         // fail set = chr(33) .. chr(33 + ph - 2)
+    return thr > 126 ? 126 : thr;              // quality_list stops at '~' (:1114)
+}
+
+// f2q_params -> RunDev; returns an F2Q_E* code and a message
+inline int fill_run(const f2q_params &p, RunDev &r, std::string &err)
+{
+    memset(&r, 0, sizeof r);
+    r.mode = p.mode; r.miss = p.miss < 0 ? 0 : p.miss; r.length = p.length;
+    r.thr = phred_threshold(p.phred); r.thr_up = phred_threshold(p.qual_up); r.thr_down = phred_threshold(p.qual_down);
+    r.msu = p.miss_search_up; r.msd = p.miss_search_down;
+    if (p.n_upstream == 0 && p.n_downstream == 0) {               // fast2q.py:538-541
+        if (p.n_start < 1 || p.n_start > F2Q_MAX_ITER) { err = "n_start must be 1..16"; return F2Q_EINVAL; }
+        r.fixed = 1; r.n_iter = p.n_start;
+        for (int i = 0; i < p.n_start; i++) r.start[i] = p.start[i];
+        return F2Q_OK;
+    }
+    // :543-558
+    if (p.n_upstream < 0 || p.n_upstream > F2Q_MAX_ITER || p.n_downstream < 0 || p.n_downstream > F2Q_MAX_ITER) {
+        err = "at most 16 upstream/downstream search sequences"; return F2Q_EINVAL;
+    }
+    if (p.n_upstream && p.n_downstream && p.n_upstream != p.n_downstream) {
+        err = "Up and Downstream sequences must be submitted in concurrent pairs"; return F2Q_EINVAL;   // :553-556
+    }
+    r.fixed = 0; r.has_up = p.n_upstream > 0; r.has_down = p.n_downstream > 0;
+    r.n_iter = p.n_upstream > p.n_downstream ? p.n_upstream : p.n_downstream;
+    for (int side = 0; side < 2; side++) {
+        const int n = side ? p.n_downstream : p.n_upstream;
+        for (int i = 0; i < n; i++) {
+            const char *s = side ? p.downstream[i] : p.upstream[i];
+            if (!s) { err = "null search sequence"; return F2Q_EINVAL; }
+            size_t l = strlen(s);
+            if (l > F2Q_ANCHOR_MAX) { err = "search sequence longer than 128"; return F2Q_EUNSUPPORTED; }
+            (side ? r.down_len : r.up_len)[i] = (int)l;
+            for (size_t k = 0; k < l; k++) (side ? r.down : r.up)[i][k] = up8((uint8_t)s[k]);      // :547,:550
+        }
+    }
+    return F2Q_OK;
+}
+
+} // namespace f2q

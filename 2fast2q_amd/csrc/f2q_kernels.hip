@@ -1,0 +1,870 @@
+// f2q_kernels.hip -- libf2q_hip.so: HIP kernels for gfx950 + the C ABI of include/f2q.h.
+//
+// Kernels
+//   k_count_fixed   fast path, fixed-offset window: one lane per read of a 256-read packed tile,
+//                   tile planes laid out [word][lane] so every load is a 1 KiB coalesced row;
+//                   Phred mask by SWAR on the quality words, 2-bit key, exact probe of the
+//                   library hash, pigeonhole + popcount search for <= m mismatches, counts by
+//                   LDS-privatised histogram (global atomics for large libraries).
+//   k_count_general any mode, any symbols: one lane per raw-byte record (the reads the packed
+//                   layout cannot carry, multi-window keys, anchored search, Extract+Count).
+//   k_synth_*       device-side generator of the SURVEY §8(d) workload (bench input).
+//   k_ec_rehash     grows the Extract+Count table.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "f2q_device.h"
+#include "f2q_host.h"
+#include "f2q_synth.h"
+
+using namespace f2q;
+
+// ===============================================================================================
+// kernels
+// ===============================================================================================
+#define F2Q_HIST_MAX 24576u     // features whose u32 histogram fits the workgroup's LDS budget (96 KiB)
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Fast path, fixed offset.  Persistent workgroups stride over the tiles.  USE_LDS: per-workgroup
+// u32 histogram in LDS, flushed once with 64-bit global atomics.
+template <bool USE_LDS>
+__global__ __launch_bounds__(F2Q_TILE) void k_count_fixed(const RunDev *__restrict__ runp,
+                                                            const LibDev *__restrict__ libp, PackedBlock pb,
+                                                            Accum acc)
+{
+    extern __shared__ uint32_t hist[];
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features;
+    if (USE_LDS) {
+        for (uint32_t i = threadIdx.x; i < nf; i += F2Q_TILE) hist[i] = 0;
+        __syncthreads();
+    }
+    unsigned long long st1 = 0, st2 = 0, st3 = 0, st4 = 0, st0 = 0;
+    for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
+        uint32_t idx = 0;
+        int res = fixed_lane(run, lib, pb, tile, threadIdx.x, idx);
+        if (res == 1 || res == 2) {
+            if (USE_LDS) atomicAdd(&hist[idx], 1u);
+            else atomicAdd(&acc.counts[idx], 1ull);
+        }
+        st0 += (res != 0); st1 += (res == 1); st2 += (res == 2); st3 += (res == 3); st4 += (res == 4);
+    }
+    st0 = wave_sum(st0); st1 = wave_sum(st1); st2 = wave_sum(st2); st3 = wave_sum(st3); st4 = wave_sum(st4);
+    if ((threadIdx.x & 63) == 0) {
+        if (st0) atomicAdd(&acc.stats[0], st0);
+        if (st1) atomicAdd(&acc.stats[1], st1);
+        if (st2) atomicAdd(&acc.stats[2], st2);
+        if (st3) atomicAdd(&acc.stats[3], st3);
+        if (st4) atomicAdd(&acc.stats[4], st4);
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nf; i += F2Q_TILE) {
+            uint32_t c = hist[i];
+            if (c) atomicAdd(&acc.counts[i], (unsigned long long)c);
+        }
+    }
+}
+
+struct RawBlock {
+    uint64_t n;
+    uint64_t first_index;                  // global index of the block's read 0
+    const uint8_t *raw;                    // per record: seq bytes then quality bytes
+    const unsigned long long *off;
+    const uint32_t *len, *qlen, *index;    // index: position inside the block (nullptr: == record id)
+};
+
+__global__ __launch_bounds__(256) void k_count_general(const RunDev *__restrict__ runp,
+                                                        const LibDev *__restrict__ libp, EcDev ec, RawBlock rb,
+                                                        Accum acc)
+{
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rb.n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *seq = rb.raw + rb.off[i];
+        const int r = (int)rb.len[i], qn = (int)rb.qlen[i];
+        const unsigned long long gi = rb.first_index + (rb.index ? rb.index[i] : i);
+        general_read(run, lib, ec, acc, seq, r, seq + r, qn, gi, st);
+    }
+    for (int k = 0; k < 5; k++) {
+        unsigned long long v = wave_sum(st[k]);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc.stats[k], v);
+    }
+}
+
+// re-insert every entry of `old` into `nw` (table growth)
+__global__ void k_ec_rehash(EcDev old, unsigned long long n_old, EcDev nw)
+{
+    unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_old) return;
+    const uint32_t len = old.ent_len[e];
+    const uint32_t *src = old.arena + old.ent_off[e];
+    const int nwords = (int)((len + 3) >> 2);
+    // same hash as key_hash() over the stored bytes
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+    for (uint32_t k = 0; k < len; k++) { h ^= (src[k >> 2] >> (8 * (k & 3))) & 0xFFu; h *= 1099511628211ull; }
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const unsigned long long fp = (h >> 32) & 0xFFFFFFFFull;
+    // keys are distinct, so plain claim-by-CAS of an empty slot is enough
+    unsigned long long ne = atomicAdd(&nw.ctr[0], 1ull);
+    unsigned long long off = atomicAdd(&nw.ctr[1], (unsigned long long)nwords);
+    for (int w = 0; w < nwords; w++) nw.arena[off + w] = src[w];
+    nw.ent_off[ne] = off; nw.ent_len[ne] = len;
+    nw.ent_count[ne] = old.ent_count[e]; nw.ent_first[ne] = old.ent_first[e];
+    uint32_t s = (uint32_t)h & nw.mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&nw.slots[s], 0ull, (fp << 32) | (ne + 1ull));
+        if (prev == 0ull) break;
+        s = (s + 1) & nw.mask;
+    }
+}
+
+// ---- synthetic workload, device side ----------------------------------------------------------
+struct SynthOut {
+    // packed planes (may be null when everything goes to the general path)
+    uint32_t *bases, *qual; uint16_t *len; uint32_t wb, wq;
+    // general records: fixed stride R for seq and R for quality
+    uint8_t *raw; unsigned long long *off; uint32_t *glen, *gqlen, *gindex;
+    unsigned long long *g_count; unsigned long long g_cap;
+    int all_general;           // 1: every read is written as a raw record
+    int window_only_clean;     // 1: only the window decides cleanliness (fixed mode)
+};
+
+__global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *__restrict__ guide_keys, SynthOut o,
+                                                     uint64_t n_slots)
+{
+    const uint64_t slot = (uint64_t)blockIdx.x * F2Q_TILE + threadIdx.x;
+    if (slot >= n_slots) return;
+    const uint64_t tile = slot / F2Q_TILE, lane = slot % F2Q_TILE;
+    if (slot >= s.n_reads) { if (o.len) o.len[slot] = (uint16_t)F2Q_LEN_SKIP; return; }
+    const uint64_t i = s.first_read + slot;
+    SynthRead r = synth_plan(s, i, [&](uint32_t g) { return guide_keys[g]; });
+    const int R = s.read_len;
+    // does the read hold a symbol the packed planes cannot carry?  (only 'N' is ever generated)
+    bool dirty = o.all_general != 0;
+    if (!dirty && r.n_pos >= 0) {
+        int p = r.wstart + r.n_pos;
+        dirty = p < R;
+    }
+    if (dirty) {
+        if (o.len) o.len[slot] = (uint16_t)F2Q_LEN_SKIP;
+        unsigned long long g = atomicAdd(o.g_count, 1ull);
+        if (g >= o.g_cap) return;                      // host checks g_count against g_cap afterwards
+        uint8_t *dst = o.raw + g * (unsigned long long)(2 * R);
+        uint64_t fw = 0;
+        for (int p = 0; p < R; p++) {
+            if ((p & 31) == 0) fw = rnd(s.seed, i, F_FLANK0 + (p >> 5));
+            dst[p] = synth_base(s, r, p, fw);
+            dst[R + p] = (p == r.qpos) ? r.qchar : (uint8_t)'I';
+        }
+        o.off[g] = g * (unsigned long long)(2 * R);
+        o.glen[g] = (uint32_t)R; o.gqlen[g] = (uint32_t)R; o.gindex[g] = (uint32_t)slot;
+        // the packed slot stays zero-filled and is skipped through the len plane
+        return;
+    }
+    if (o.len) o.len[slot] = (uint16_t)R;
+    uint32_t *bp = o.bases + (tile * o.wb) * F2Q_TILE + lane;
+    uint32_t *qp = o.qual + (tile * o.wq) * F2Q_TILE + lane;
+    uint64_t fw = 0;
+    uint32_t bw = 0, qw = 0;
+    for (int p = 0; p < R; p++) {
+        if ((p & 31) == 0) fw = rnd(s.seed, i, F_FLANK0 + (p >> 5));
+        uint8_t c = synth_base(s, r, p, fw);
+        uint32_t code = base_code(c); if (code > 3u) code = 0;
+        bw |= code << (2 * (p & 15));
+        qw |= (uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') << (8 * (p & 3));
+        if ((p & 15) == 15 || p == R - 1) { bp[(uint64_t)(p >> 4) * F2Q_TILE] = bw; bw = 0; }
+        if ((p & 3) == 3 || p == R - 1) { qp[(uint64_t)(p >> 2) * F2Q_TILE] = qw; qw = 0; }
+    }
+}
+
+// ===============================================================================================
+// host side
+// ===============================================================================================
+struct DevBuf {
+    void *p = nullptr; size_t n = 0;
+};
+
+struct f2q_block {
+    PackedBlock pb{};
+    RawBlock rb{};
+    std::vector<void *> allocs;
+    uint64_t n_reads = 0, n_general = 0, dev_bytes = 0;
+};
+
+struct f2q_ctx {
+    f2q_params prm{};
+    std::vector<std::string> up_s, down_s;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    RunDev run_h{};
+    RunDev *run_d = nullptr;
+    PackPlan plan{};
+    // library
+    bool have_lib = false;
+    HostIndex ix;
+    LibDev lib_h{};
+    LibDev *lib_d = nullptr;
+    std::vector<void *> lib_allocs;
+    uint64_t *guide_keys_d = nullptr;
+    // accumulators: counts[n_features] then stats[5]
+    unsigned long long *acc_d = nullptr;
+    uint64_t acc_n = 0;
+    // Extract+Count table
+    EcDev ec{};
+    std::vector<void *> ec_allocs;
+    uint64_t ec_slots = 0;
+    uint64_t reads_seen = 0;             // global read index of the next block's read 0
+    int n_cu = 256;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(f2q_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIPC(ctx, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, F2Q_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class T>
+static int dev_upload(f2q_ctx *c, const T *src, size_t n, T **dst, std::vector<void *> &owner)
+{
+    void *p = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPC(c, hipMalloc(&p, bytes));
+    owner.push_back(p);
+    if (n) HIPC(c, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dst = (T *)p;
+    return F2Q_OK;
+}
+template <class T>
+static int dev_alloc(f2q_ctx *c, size_t n, T **dst, std::vector<void *> &owner, int fill = -1)
+{
+    void *p = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPC(c, hipMalloc(&p, bytes));
+    owner.push_back(p);
+    if (fill >= 0) HIPC(c, hipMemsetAsync(p, fill, bytes, c->stream));
+    *dst = (T *)p;
+    return F2Q_OK;
+}
+static void free_all(std::vector<void *> &v)
+{
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+extern "C" int f2q_version(void) { return F2Q_ABI_VERSION; }
+
+extern "C" const char *f2q_last_error(const f2q_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" void *f2q_stream(f2q_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+static int setup_run(f2q_ctx *c)
+{
+    f2q_params p = c->prm;
+    for (int i = 0; i < p.n_upstream && i < F2Q_MAX_ITER; i++) p.upstream[i] = c->up_s[i].c_str();
+    for (int i = 0; i < p.n_downstream && i < F2Q_MAX_ITER; i++) p.downstream[i] = c->down_s[i].c_str();
+    std::string err;
+    int rc = fill_run(p, c->run_h, err);
+    if (rc) return fail(c, rc, err);
+    c->plan = make_plan(c->run_h);
+    return F2Q_OK;
+}
+
+static int upload_lib(f2q_ctx *c)
+{
+    free_all(c->lib_allocs);
+    LibDev &L = c->lib_h;
+    memset(&L, 0, sizeof L);
+    L.n_features = c->ix.n_features;
+    L.n_irregular = c->ix.n_irregular;
+    memcpy(L.grp, c->ix.grp, sizeof L.grp);
+    uint64_t *tk; uint32_t *ti; uint8_t *fb; uint32_t *fo; uint32_t *ir; uint64_t *gk;
+    int rc;
+    if ((rc = dev_upload(c, c->ix.tab_keys.data(), c->ix.tab_keys.size(), &tk, c->lib_allocs))) return rc;
+    if ((rc = dev_upload(c, c->ix.tab_idx.data(), c->ix.tab_idx.size(), &ti, c->lib_allocs))) return rc;
+    if ((rc = dev_upload(c, c->ix.feat_bytes.data(), c->ix.feat_bytes.size(), &fb, c->lib_allocs))) return rc;
+    if ((rc = dev_upload(c, c->ix.feat_off.data(), c->ix.feat_off.size(), &fo, c->lib_allocs))) return rc;
+    if ((rc = dev_upload(c, c->ix.irr_ids.data(), c->ix.irr_ids.size(), &ir, c->lib_allocs))) return rc;
+    if ((rc = dev_upload(c, c->ix.key2.data(), c->ix.key2.size(), &gk, c->lib_allocs))) return rc;
+    L.tab_keys = tk; L.tab_idx = ti; L.feat_bytes = fb; L.feat_off = fo; L.irr_ids = ir;
+    c->guide_keys_d = gk;
+    LibDev *ld;
+    if ((rc = dev_upload(c, &L, 1, &ld, c->lib_allocs))) return rc;
+    c->lib_d = ld;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return F2Q_OK;
+}
+
+static int alloc_acc(f2q_ctx *c, uint64_t n_features)
+{
+    if (c->acc_d) { (void)hipFree(c->acc_d); c->acc_d = nullptr; }
+    c->acc_n = n_features + 5;
+    HIPC(c, hipMalloc((void **)&c->acc_d, c->acc_n * sizeof(unsigned long long)));
+    HIPC(c, hipMemsetAsync(c->acc_d, 0, c->acc_n * sizeof(unsigned long long), c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return F2Q_OK;
+}
+
+extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
+{
+    if (!p || !out) return fail(nullptr, F2Q_EINVAL, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, F2Q_ENODEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (p->device < 0 || p->device >= ndev) return fail(nullptr, F2Q_EINVAL, "device ordinal out of range");
+    if (p->mode != 0 && p->mode != 1) return fail(nullptr, F2Q_EINVAL, "mode must be 0 (C) or 1 (EC)");
+    f2q_ctx *c = new f2q_ctx();
+    c->prm = *p;
+    for (int i = 0; i < p->n_upstream && i < F2Q_MAX_ITER; i++) c->up_s.push_back(p->upstream[i] ? p->upstream[i] : "");
+    for (int i = 0; i < p->n_downstream && i < F2Q_MAX_ITER; i++) c->down_s.push_back(p->downstream[i] ? p->downstream[i] : "");
+    c->device = p->device;
+    int rc = setup_run(c);
+    if (rc) { g_create_err = c->err; delete c; return rc; }
+#define CREATE_HIP(call)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            g_create_err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            f2q_destroy(c);                                                                         \
+            return F2Q_EHIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+    CREATE_HIP(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_HIP(hipEventCreate(&c->ev_a)); CREATE_HIP(hipEventCreate(&c->ev_b));
+    CREATE_HIP(hipEventCreate(&c->ev_k0)); CREATE_HIP(hipEventCreate(&c->ev_k1));
+    CREATE_HIP(hipMalloc((void **)&c->run_d, sizeof(RunDev)));
+    CREATE_HIP(hipMemcpyAsync(c->run_d, &c->run_h, sizeof(RunDev), hipMemcpyHostToDevice, c->stream));
+    // an empty library so that EC mode (and a Counter run before set_features fails cleanly) has valid pointers
+    build_index(c->ix, "", (const uint32_t[]){0}, 0, c->run_h.miss);
+    rc = upload_lib(c);
+    if (!rc) rc = alloc_acc(c, 0);
+    if (rc) { g_create_err = c->err; f2q_destroy(c); return rc; }
+    *out = c;
+    return F2Q_OK;
+}
+
+extern "C" void f2q_destroy(f2q_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_all(c->lib_allocs); free_all(c->ec_allocs);
+    if (c->acc_d) (void)hipFree(c->acc_d);
+    if (c->run_d) (void)hipFree(c->run_d);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *offs, uint32_t n)
+{
+    if (!c || !offs || (!seqs && n)) return fail(c, F2Q_EINVAL, "null argument");
+    if (c->prm.mode != 0) return fail(c, F2Q_ESTATE, "Extract+Count mode takes no feature library (fast2q.py:1701)");
+    HIPC(c, hipSetDevice(c->device));
+    for (uint32_t i = 0; i < n; i++) if (offs[i + 1] < offs[i]) return fail(c, F2Q_EINVAL, "offsets must be non-decreasing");
+    build_index(c->ix, seqs ? seqs : "", offs, n, c->run_h.miss);
+    int rc = upload_lib(c);
+    if (rc) return rc;
+    rc = alloc_acc(c, n);
+    if (rc) return rc;
+    c->have_lib = true;
+    return F2Q_OK;
+}
+
+extern "C" int f2q_reset_counts(f2q_ctx *c)
+{
+    if (!c) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemsetAsync(c->acc_d, 0, c->acc_n * sizeof(unsigned long long), c->stream));
+    if (c->prm.mode == 1) { free_all(c->ec_allocs); memset(&c->ec, 0, sizeof c->ec); c->ec_slots = 0; }
+    c->reads_seen = 0;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return F2Q_OK;
+}
+
+extern "C" int f2q_read_counts(f2q_ctx *c, int64_t *counts, int64_t stats[5])
+{
+    if (!c) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    std::vector<unsigned long long> h(c->acc_n);
+    HIPC(c, hipMemcpyAsync(h.data(), c->acc_d, c->acc_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (counts) for (uint64_t i = 0; i + 5 < c->acc_n; i++) counts[i] = (int64_t)h[i];
+    if (stats) for (int k = 0; k < 5; k++) stats[k] = (int64_t)h[c->acc_n - 5 + k];
+    return F2Q_OK;
+}
+
+extern "C" int f2q_counts_device_ptr(f2q_ctx *c, void **dptr, uint64_t *n_int64)
+{
+    if (!c || !dptr || !n_int64) return F2Q_EINVAL;
+    *dptr = c->acc_d; *n_int64 = c->acc_n;
+    return F2Q_OK;
+}
+
+// ---- Extract+Count table management -----------------------------------------------------------
+static int ec_alloc(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t max_entries, uint64_t arena_words)
+{
+    memset(&e, 0, sizeof e);
+    uint64_t slots = 1024;
+    while (slots < 2 * max_entries) slots <<= 1;
+    if (slots > (1ull << 32)) return fail(c, F2Q_ENOMEM, "Extract+Count table would exceed 2^32 slots");
+    int rc;
+    if ((rc = dev_alloc(c, slots, &e.slots, owner, 0))) return rc;
+    if ((rc = dev_alloc(c, max_entries, &e.ent_off, owner))) return rc;
+    if ((rc = dev_alloc(c, max_entries, &e.ent_len, owner))) return rc;
+    if ((rc = dev_alloc(c, max_entries, &e.ent_count, owner, 0))) return rc;
+    if ((rc = dev_alloc(c, max_entries, &e.ent_first, owner, 0xFF))) return rc;
+    if ((rc = dev_alloc(c, arena_words, &e.arena, owner))) return rc;
+    if ((rc = dev_alloc(c, (size_t)4, &e.ctr, owner, 0))) return rc;
+    e.mask = (uint32_t)(slots - 1); e.max_entries = (uint32_t)std::min<uint64_t>(max_entries, 0xFFFFFFFEull);
+    e.arena_words = arena_words;
+    return F2Q_OK;
+}
+
+// make room for `reads` more reads whose keys total at most `key_bytes` bytes
+static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
+{
+    unsigned long long ctr[4] = {0, 0, 0, 0};
+    if (c->ec.slots) {
+        HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    const uint64_t need_e = ctr[0] + reads + 16, need_w = ctr[1] + (key_bytes + 3) / 4 + reads + 16;
+    if (c->ec.slots && need_e <= c->ec.max_entries && need_w <= c->ec.arena_words) return F2Q_OK;
+    uint64_t ne = std::max<uint64_t>(need_e * 2, 1u << 16), nw = std::max<uint64_t>(need_w * 2, 1u << 18);
+    EcDev fresh; std::vector<void *> owner;
+    int rc = ec_alloc(c, fresh, owner, ne, nw);
+    if (rc) { free_all(owner); return rc; }
+    if (c->ec.slots && ctr[0]) {
+        hipLaunchKernelGGL(k_ec_rehash, dim3((unsigned)((ctr[0] + 255) / 256)), dim3(256), 0, c->stream, c->ec, ctr[0], fresh);
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    free_all(c->ec_allocs);
+    c->ec_allocs = owner; c->ec = fresh;
+    return F2Q_OK;
+}
+
+// ---- launching ----------------------------------------------------------------------------------
+static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
+{
+    if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
+    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5)};
+    if (c->prm.mode == 1 && b->rb.n) {
+        // worst case every read inserts a new key made of all its windows
+        uint64_t key_bytes = b->dev_bytes;   // upper bound: no key is longer than the read's bytes + separators
+        int rc = ec_reserve(c, b->rb.n, key_bytes + (uint64_t)b->rb.n * F2Q_MAX_ITER);
+        if (rc) return rc;
+    }
+    uint32_t launches = 0;
+    HIPC(c, hipEventRecord(c->ev_k0, c->stream));
+    if (b->pb.n_tiles) {
+        const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * 8u);
+        const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
+        if (lds) {
+            size_t shmem = std::max<size_t>(4, (size_t)c->lib_h.n_features * 4);
+            hipLaunchKernelGGL(k_count_fixed<true>, dim3(grid), dim3(F2Q_TILE), shmem, c->stream, c->run_d, c->lib_d, b->pb, acc);
+        } else {
+            hipLaunchKernelGGL(k_count_fixed<false>, dim3(grid), dim3(F2Q_TILE), 0, c->stream, c->run_d, c->lib_d, b->pb, acc);
+        }
+        HIPC(c, hipGetLastError());
+        launches++;
+    }
+    if (b->rb.n) {
+        RawBlock rb = b->rb;
+        rb.first_index += c->reads_seen;
+        const uint64_t wg = (rb.n + 255) / 256;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(wg, (uint64_t)c->n_cu * 16u);
+        hipLaunchKernelGGL(k_count_general, dim3(grid), dim3(256), 0, c->stream, c->run_d, c->lib_d, c->ec, rb, acc);
+        HIPC(c, hipGetLastError());
+        launches++;
+    }
+    HIPC(c, hipEventRecord(c->ev_k1, c->stream));
+    c->reads_seen += b->n_reads;
+    if (t) {
+        HIPC(c, hipEventSynchronize(c->ev_k1));
+        float ms = 0;
+        HIPC(c, hipEventElapsedTime(&ms, c->ev_k0, c->ev_k1));
+        t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
+        t->fast_reads = b->n_reads - b->n_general; t->launches = launches;
+    }
+    if (c->prm.mode == 1 && b->rb.n) {
+        unsigned long long ctr[4];
+        HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error)");
+    }
+    return F2Q_OK;
+}
+
+extern "C" int f2q_count_resident(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
+{
+    if (!c || !b) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    if (t) { memset(t, 0, sizeof *t); HIPC(c, hipEventRecord(c->ev_a, c->stream)); }
+    int rc = launch_block(c, b, t);
+    if (rc) return rc;
+    if (t) {
+        HIPC(c, hipEventRecord(c->ev_b, c->stream));
+        HIPC(c, hipEventSynchronize(c->ev_b));
+        float ms = 0; HIPC(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+        t->total_ms = ms;
+    }
+    return F2Q_OK;
+}
+
+extern "C" void f2q_block_free(f2q_ctx *c, f2q_block *b)
+{
+    if (!b) return;
+    if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    free_all(b->allocs);
+    delete b;
+}
+
+extern "C" int f2q_block_info(const f2q_block *b, uint64_t *n_reads, uint64_t *n_general, uint64_t *device_bytes)
+{
+    if (!b) return F2Q_EINVAL;
+    if (n_reads) *n_reads = b->n_reads;
+    if (n_general) *n_general = b->n_general;
+    if (device_bytes) *device_bytes = b->dev_bytes;
+    return F2Q_OK;
+}
+
+static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_block **out)
+{
+    HostPacked hp;
+    pack_records(c->plan, recs, hp);
+    f2q_block *b = new f2q_block();
+    b->n_reads = recs.size(); b->n_general = hp.g_len.size();
+    int rc = F2Q_OK;
+    do {
+        if (hp.n_tiles) {
+            uint32_t *db, *dq; uint16_t *dl;
+            if ((rc = dev_upload(c, hp.bases.data(), hp.bases.size(), &db, b->allocs))) break;
+            if ((rc = dev_upload(c, hp.qual.data(), hp.qual.size(), &dq, b->allocs))) break;
+            if ((rc = dev_upload(c, hp.len.data(), hp.len.size(), &dl, b->allocs))) break;
+            b->pb.n_slots = (uint64_t)hp.n_tiles * F2Q_TILE; b->pb.n_tiles = hp.n_tiles;
+            b->pb.wb = hp.wb; b->pb.wq = hp.wq; b->pb.rmax = hp.rmax;
+            b->pb.bases = db; b->pb.qual = dq; b->pb.len = dl;
+            b->dev_bytes += hp.bases.size() * 4 + hp.qual.size() * 4 + hp.len.size() * 2;
+        }
+        if (!hp.g_len.empty()) {
+            uint8_t *dr; unsigned long long *doff; uint32_t *dlen, *dqlen, *dix;
+            if ((rc = dev_upload(c, hp.raw.data(), hp.raw.size(), &dr, b->allocs))) break;
+            if ((rc = dev_upload(c, hp.g_off.data(), hp.g_off.size(), &doff, b->allocs))) break;
+            if ((rc = dev_upload(c, hp.g_len.data(), hp.g_len.size(), &dlen, b->allocs))) break;
+            if ((rc = dev_upload(c, hp.g_qlen.data(), hp.g_qlen.size(), &dqlen, b->allocs))) break;
+            if ((rc = dev_upload(c, hp.g_index.data(), hp.g_index.size(), &dix, b->allocs))) break;
+            b->rb.n = hp.g_len.size(); b->rb.raw = dr; b->rb.off = doff; b->rb.len = dlen; b->rb.qlen = dqlen; b->rb.index = dix;
+            b->dev_bytes += hp.raw.size() + hp.g_len.size() * 20;
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);      // host staging vectors die with this frame
+        if (e != hipSuccess) { rc = fail(c, F2Q_EHIP, hipGetErrorString(e)); break; }
+    } while (0);
+    if (rc) { free_all(b->allocs); delete b; return rc; }
+    *out = b;
+    return F2Q_OK;
+}
+
+extern "C" int f2q_block_from_fastq(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, f2q_block **out)
+{
+    if (!c || !out || (!fastq && nbytes)) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    std::vector<Rec> recs;
+    frame_fastq(fastq, nbytes, recs);
+    return block_from_records(c, recs, out);
+}
+
+extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_timing *t)
+{
+    if (!c || (!fastq && nbytes)) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    if (t) { memset(t, 0, sizeof *t); HIPC(c, hipEventRecord(c->ev_a, c->stream)); }
+    std::vector<Rec> recs;
+    size_t used = frame_fastq(fastq, nbytes, recs);
+    if (consumed) *consumed = used;
+    if (recs.empty()) return F2Q_OK;
+    f2q_block *b = nullptr;
+    int rc = block_from_records(c, recs, &b);
+    if (rc) return rc;
+    rc = launch_block(c, b, t);
+    if (!rc && t) {
+        hipError_t e = hipEventRecord(c->ev_b, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev_b);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev_a, c->ev_b);
+        if (e != hipSuccess) rc = fail(c, F2Q_EHIP, hipGetErrorString(e));
+        t->total_ms = ms;
+    }
+    f2q_block_free(c, b);
+    return rc;
+}
+
+// reads_counter's file half (fast2q.py:560-578): gzip or plain by extension; streamed in blocks
+extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
+{
+    if (!c || !path) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    const size_t CH = (size_t)256 << 20;
+    gzFile f = gzopen(path, "rb");               // zlib reads plain files transparently
+    if (!f) return fail(c, F2Q_EIO, std::string("cannot open ") + path);
+    gzbuffer(f, 1 << 20);
+    std::vector<uint8_t> buf(CH);
+    size_t have = 0;
+    f2q_timing sum; memset(&sum, 0, sizeof sum);
+    int rc = F2Q_OK; bool truncated = false;
+    for (;;) {
+        int got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
+        if (got < 0) { truncated = true; got = 0; }
+        have += (size_t)got;
+        const bool eof = (got == 0);
+        if (have == 0) break;
+        size_t used = 0; f2q_timing one;
+        if (eof) {
+            rc = f2q_count_block(c, buf.data(), have, &used, &one);     // trailing partial record is dropped (:392)
+            used = have;
+        } else {
+            // only hand over whole lines: cut at the last newline so a line is never split between blocks
+            size_t cut = have;
+            while (cut > 0 && buf[cut - 1] != '\n') cut--;
+            if (cut == 0) { if (have == buf.size()) buf.resize(buf.size() * 2); continue; }
+            rc = f2q_count_block(c, buf.data(), cut, &used, &one);
+        }
+        if (rc) break;
+        sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
+        sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
+        memmove(buf.data(), buf.data() + used, have - used);
+        have -= used;
+        if (eof) break;
+        if (have == buf.size()) buf.resize(buf.size() * 2);
+    }
+    int zerr = 0; (void)gzerror(f, &zerr);
+    if (zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) truncated = true;
+    gzclose(f);
+    if (t) *t = sum;
+    if (rc) return rc;
+    if (truncated) return fail(c, F2Q_ETRUNCATED, std::string(path) + " is an incomplete or corrupted gzip file");
+    return F2Q_OK;
+}
+
+// ---- synthetic workload ---------------------------------------------------------------------------
+static int synth_to_dev(f2q_ctx *c, const f2q_synth *s, SynthDev &d)
+{
+    memset(&d, 0, sizeof d);
+    if (!c->have_lib || c->ix.n_features == 0) return fail(c, F2Q_ESTATE, "synthetic reads need a feature library (f2q_set_features)");
+    uint32_t glen = c->ix.feat_off[1] - c->ix.feat_off[0];
+    for (uint32_t f = 0; f < c->ix.n_features; f++) {
+        uint64_t k;
+        if (c->ix.feat_off[f + 1] - c->ix.feat_off[f] != glen || !feature_key(c->ix.feat_bytes.data() + c->ix.feat_off[f], glen, k))
+            return fail(c, F2Q_EUNSUPPORTED, "synthetic reads need a uniform-length ACGT library (<= 31 bp)");
+    }
+    d.seed = s->seed; d.n_reads = s->n_reads; d.first_read = s->first_read;
+    d.read_len = s->read_len; d.start = s->start; d.cassette = s->cassette; d.max_offset = s->max_offset;
+    d.glen = (int)glen; d.n_guides = (int)c->ix.n_features;
+    d.t_sub = s->t_sub; d.t_rand = s->t_rand; d.t_n = s->t_n; d.t_lowq = s->t_lowq; d.t_q29 = s->t_q29; d.t_q28 = s->t_q28;
+    if (s->read_len < 1 || s->read_len > F2Q_PACK_MAXLEN) return fail(c, F2Q_EINVAL, "read_len must be 1..512");
+    if (s->cassette) {
+        size_t ul = s->up ? strlen(s->up) : 0, dl = s->down ? strlen(s->down) : 0;
+        if (ul > 63 || dl > 63) return fail(c, F2Q_EINVAL, "cassette flanks longer than 63");
+        d.up_len = (int)ul; d.down_len = (int)dl;
+        if (ul) memcpy(d.up, s->up, ul);
+        if (dl) memcpy(d.down, s->down, dl);
+    }
+    return F2Q_OK;
+}
+
+extern "C" int f2q_synth_library(uint64_t seed, uint32_t n, uint32_t length, char *out)
+{
+    if (!out || length < 1 || length > 32) return F2Q_EINVAL;
+    // tests/synth.py make_library: candidate k = bases of rnd(seed, k, 0); duplicates skipped
+    std::vector<uint64_t> seen; seen.reserve(n);
+    std::vector<uint64_t> sorted;
+    uint64_t k = 0; uint32_t made = 0;
+    const uint64_t mask = length >= 32 ? ~0ull : ((1ull << (2 * length)) - 1ull);
+    // open-addressing set
+    uint64_t cap = 16; while (cap < 4ull * n) cap <<= 1;
+    std::vector<uint64_t> set(cap, ~0ull);
+    std::vector<uint8_t> used(cap, 0);
+    while (made < n) {
+        uint64_t v = rnd(seed, k++, 0) & mask;
+        uint64_t h = mix64(v) & (cap - 1);
+        bool dup = false;
+        while (used[h]) { if (set[h] == v) { dup = true; break; } h = (h + 1) & (cap - 1); }
+        if (dup) continue;
+        used[h] = 1; set[h] = v;
+        for (uint32_t j = 0; j < length; j++) out[(size_t)made * length + j] = "ACGT"[(v >> (2 * j)) & 3];
+        made++;
+        if (k > 64ull * n + 1024) return F2Q_EINVAL;    // sequence space exhausted
+    }
+    return F2Q_OK;
+}
+
+extern "C" int f2q_synth_fastq(f2q_ctx *c, const f2q_synth *s, uint64_t lo, uint64_t hi, uint8_t *buf, size_t *nbytes)
+{
+    if (!c || !s || !nbytes || hi < lo) return F2Q_EINVAL;
+    SynthDev d; int rc = synth_to_dev(c, s, d);
+    if (rc) return rc;
+    const int R = d.read_len;
+    size_t need = 0;
+    for (uint64_t i = lo; i < hi; i++) {
+        char name[32]; int nl = snprintf(name, sizeof name, "@r%llu\n", (unsigned long long)i);
+        need += (size_t)nl + (size_t)R + 3 + (size_t)R + 1;
+    }
+    if (!buf) { *nbytes = need; return F2Q_OK; }
+    if (*nbytes < need) { *nbytes = need; return fail(c, F2Q_EINVAL, "buffer too small"); }
+    size_t o = 0;
+    const uint64_t *keys = c->ix.key2.data();
+    for (uint64_t i = lo; i < hi; i++) {
+        SynthRead r = synth_plan(d, i, [&](uint32_t g) { return keys[g]; });
+        o += (size_t)snprintf((char *)buf + o, 32, "@r%llu\n", (unsigned long long)i);
+        uint64_t fw = 0;
+        for (int p = 0; p < R; p++) {
+            if ((p & 31) == 0) fw = rnd(d.seed, i, F_FLANK0 + (p >> 5));
+            buf[o + p] = synth_base(d, r, p, fw);
+        }
+        o += (size_t)R;
+        buf[o++] = '\n'; buf[o++] = '+'; buf[o++] = '\n';
+        for (int p = 0; p < R; p++) buf[o + p] = (p == r.qpos) ? r.qchar : (uint8_t)'I';
+        o += (size_t)R;
+        buf[o++] = '\n';
+    }
+    *nbytes = o;
+    return F2Q_OK;
+}
+
+extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
+{
+    if (!c || !s || !out) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    SynthDev d; int rc = synth_to_dev(c, s, d);
+    if (rc) return rc;
+    const int R = d.read_len;
+    f2q_block *b = new f2q_block();
+    b->n_reads = s->n_reads;
+    const bool fast = c->plan.fast_fixed;
+    SynthOut o; memset(&o, 0, sizeof o);
+    o.all_general = fast ? 0 : 1;
+    const uint64_t n_tiles = (s->n_reads + F2Q_TILE - 1) / F2Q_TILE;
+    const uint64_t n_slots = n_tiles * F2Q_TILE;
+    // general-path capacity: everything, or the expected 'N' share with a wide margin
+    double pn = (double)d.t_n / 4294967296.0;
+    uint64_t gcap = fast ? (uint64_t)((double)s->n_reads * pn * 1.5 + 6.0 * sqrt((double)s->n_reads * pn + 1.0) + 1024.0) : s->n_reads;
+    if (gcap > s->n_reads) gcap = s->n_reads;
+    if (gcap == 0) gcap = 1;
+    do {
+        if (fast) {
+            o.wb = (uint32_t)((R + 15) / 16); o.wq = (uint32_t)((R + 3) / 4);
+            if ((rc = dev_alloc(c, (size_t)n_tiles * o.wb * F2Q_TILE, &o.bases, b->allocs, 0))) break;
+            if ((rc = dev_alloc(c, (size_t)n_tiles * o.wq * F2Q_TILE, &o.qual, b->allocs, 0))) break;
+            if ((rc = dev_alloc(c, (size_t)n_slots, &o.len, b->allocs))) break;
+            b->dev_bytes += (uint64_t)n_tiles * (o.wb + o.wq) * F2Q_TILE * 4 + n_slots * 2;
+        }
+        if ((rc = dev_alloc(c, (size_t)gcap * 2 * R + 8, &o.raw, b->allocs))) break;
+        if ((rc = dev_alloc(c, (size_t)gcap, &o.off, b->allocs))) break;
+        if ((rc = dev_alloc(c, (size_t)gcap, &o.glen, b->allocs))) break;
+        if ((rc = dev_alloc(c, (size_t)gcap, &o.gqlen, b->allocs))) break;
+        if ((rc = dev_alloc(c, (size_t)gcap, &o.gindex, b->allocs))) break;
+        if ((rc = dev_alloc(c, (size_t)1, &o.g_count, b->allocs, 0))) break;
+        o.g_cap = gcap;
+        hipLaunchKernelGGL(k_synth, dim3((unsigned)n_tiles), dim3(F2Q_TILE), 0, c->stream, d, c->guide_keys_d, o, n_slots);
+        hipError_t e = hipGetLastError();
+        unsigned long long g = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&g, o.g_count, sizeof g, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(c, F2Q_EHIP, hipGetErrorString(e)); break; }
+        if (g > gcap) { rc = fail(c, F2Q_ENOMEM, "synthetic general-path capacity exceeded"); break; }
+        b->n_general = g;
+        if (fast) {
+            b->pb.n_slots = n_slots; b->pb.n_tiles = (uint32_t)n_tiles; b->pb.wb = o.wb; b->pb.wq = o.wq; b->pb.rmax = (uint32_t)R;
+            b->pb.bases = o.bases; b->pb.qual = o.qual; b->pb.len = o.len;
+        }
+        b->rb.n = g; b->rb.raw = o.raw; b->rb.off = o.off; b->rb.len = o.glen; b->rb.qlen = o.gqlen; b->rb.index = o.gindex;
+        b->rb.first_index = 0;
+        b->dev_bytes += g * (uint64_t)(2 * R + 20);
+    } while (0);
+    if (rc) { free_all(b->allocs); delete b; return rc; }
+    *out = b;
+    return F2Q_OK;
+}
+
+// ---- Extract+Count results ----------------------------------------------------------------------
+extern "C" int f2q_ec_size(f2q_ctx *c, uint64_t *n_keys, uint64_t *n_bytes)
+{
+    if (!c || !n_keys || !n_bytes) return F2Q_EINVAL;
+    *n_keys = 0; *n_bytes = 0;
+    if (c->prm.mode != 1) return fail(c, F2Q_ESTATE, "not in Extract+Count mode");
+    if (!c->ec.slots) return F2Q_OK;
+    HIPC(c, hipSetDevice(c->device));
+    unsigned long long ctr[4];
+    HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> len(ctr[0]);
+    if (ctr[0]) HIPC(c, hipMemcpy(len.data(), c->ec.ent_len, ctr[0] * 4, hipMemcpyDeviceToHost));
+    uint64_t nb = 0; for (uint32_t l : len) nb += l;
+    *n_keys = ctr[0]; *n_bytes = nb;
+    return F2Q_OK;
+}
+
+extern "C" int f2q_ec_fetch(f2q_ctx *c, char *keys, uint64_t *offs, int64_t *counts, uint64_t *first_read)
+{
+    if (!c || !offs) return F2Q_EINVAL;
+    if (c->prm.mode != 1) return fail(c, F2Q_ESTATE, "not in Extract+Count mode");
+    offs[0] = 0;
+    if (!c->ec.slots) return F2Q_OK;
+    HIPC(c, hipSetDevice(c->device));
+    unsigned long long ctr[4];
+    HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const uint64_t n = ctr[0];
+    if (!n) return F2Q_OK;
+    std::vector<uint32_t> len(n), arena(ctr[1] ? ctr[1] : 1);
+    std::vector<unsigned long long> off(n), cnt(n), first(n);
+    HIPC(c, hipMemcpy(len.data(), c->ec.ent_len, n * 4, hipMemcpyDeviceToHost));
+    HIPC(c, hipMemcpy(off.data(), c->ec.ent_off, n * 8, hipMemcpyDeviceToHost));
+    HIPC(c, hipMemcpy(cnt.data(), c->ec.ent_count, n * 8, hipMemcpyDeviceToHost));
+    HIPC(c, hipMemcpy(first.data(), c->ec.ent_first, n * 8, hipMemcpyDeviceToHost));
+    if (ctr[1]) HIPC(c, hipMemcpy(arena.data(), c->ec.arena, ctr[1] * 4, hipMemcpyDeviceToHost));
+    uint64_t o = 0;
+    for (uint64_t e = 0; e < n; e++) {
+        if (keys) memcpy(keys + o, (const uint8_t *)(arena.data() + off[e]), len[e]);
+        o += len[e]; offs[e + 1] = o;
+        if (counts) counts[e] = (int64_t)cnt[e];
+        if (first_read) first_read[e] = first[e];
+    }
+    return F2Q_OK;
+}

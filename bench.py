@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s of the 2FAST2Q counting hot path on MI355X.
+
+A step = one pass of the hot path (Phred mask -> window -> <=m-mismatch match -> count) over one
+device-resident batch of synthetic 150-bp reads, followed by the all-reduce of the
+int64 count vector when N > 1.  Workload = BASELINE.json configs[2], the configuration the metric is
+quoted on: 50M x 150 bp reads vs 10k x 20 bp guides, --m 1 --ph 30, per GPU (weak scaling: config 4 is
+the same per-GPU load on 8 GPUs with a 100k library).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (reads per GPU, guides, miss, synth spec extras, counter extras)
+    "cfg2_10M_1k_m0": dict(n_reads=10_000_000, n_guides=1000, miss=0, lib_seed=0xF2A5 + 2),
+    "cfg3_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 3),
+    "cfg4_50M_100k_m1": dict(n_reads=50_000_000, n_guides=100000, miss=1, lib_seed=0xF2A5 + 4),
+}
+B_ALG = 188           # algorithmic bytes per 150-bp read: 38 B of 2-bit bases + 150 quality bytes
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(pkg, guides, miss, seconds_target=15.0):
+    """The oracle (C port of the reference algorithm) timed on this host's cores over a bounded sample of
+    the same workload."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    n = 400_000 * max(1, threads // 4)
+    with pkg.Counter(features=guides, miss=miss) as c:
+        fq = bytes(c.synth_fastq(seed=1, n_reads=n, read_len=150))
+    feats = [(str(i), s) for i, s in enumerate(guides)]
+    t0 = time.perf_counter()
+    orc = O.count_fastq_parallel(fq, threads, features=feats, miss=miss)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e6, "unit": "Mreads/s", "cores": threads, "kind": "port",
+            "sample": f"{n} reads of the same synthetic stream, FASTQ text in memory, {threads} threads, "
+                      f"oracle/f2q_oracle.c (dict hit + early-exit all-vs-all with memo caches)",
+            "seconds": dt, "reads_checked": orc.stats()[0]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3_50M_10k_m1", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the counting path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    pkg = importlib.import_module("2fast2q_amd")
+    w = dict(WORKLOADS[a.workload])
+    if a.reads:
+        w["n_reads"] = a.reads
+    guides = pkg.binding.synth_library(w["lib_seed"], w["n_guides"], 20)
+    c = pkg.Counter(features=guides, miss=w["miss"], phred=30, length=20, start="0", device=local)
+    n = w["n_reads"]
+    blk = c.synth_create(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=150)
+    info = blk.info()
+
+    # the device accumulator as a torch tensor, so RCCL can all-reduce it in place
+    ptr, n64 = c.counts_device_ptr()
+
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (n64,), "typestr": "<i8", "data": (ptr, False), "version": 3}
+    acc = torch.as_tensor(_Arr(), device=torch.device("cuda", local))
+    stream = torch.cuda.ExternalStream(c.stream(), device=torch.device("cuda", local))
+
+    def step():
+        t = c.count_resident(blk)          # launches on the context's stream, waits on its HIP events
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(acc)
+        return t
+
+    for _ in range(a.warmup):
+        c.reset(); step()
+    kern_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        kern_ms.append(step()["kernel_ms"])
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        total_reads = n * world * a.steps
+        k_ms = sum(kern_ms) / len(kern_ms)
+        achieved = B_ALG * n / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mreads/sec matched (150 bp, 20 bp feature, m=%d)" % w["miss"],
+            "value": total_reads / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 (2-bit packed bases) / u8 qualities", "data": "synthetic",
+            "config": {"workload": a.workload, "reads_per_gpu": n, "read_len": 150, "guides": w["n_guides"],
+                       "guide_len": 20, "miss": w["miss"], "phred": 30, "start": 0,
+                       "general_path_reads_per_gpu": info["n_general"], "sharding": f"dp{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "bytes_per_read": B_ALG},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, guides, w["miss"])
+        print(json.dumps(out))
+    blk.free(); c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+// tests/emu/f2q_emu.cpp -- TEST INFRASTRUCTURE.  Compiles the product's per-lane logic
+// (2fast2q_amd/csrc/f2q_device.h, f2q_host.h, f2q_synth.h) with g++ and runs it lane by lane on
+// the host, so that the logic the HIP kernels execute can be checked against the oracle on a
+// machine without a GPU.  The product never uses this file; libf2q_hip.so has no host path.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../2fast2q_amd/csrc/f2q_device.h"
+#include "../../2fast2q_amd/csrc/f2q_host.h"
+#include "../../2fast2q_amd/csrc/f2q_synth.h"
+
+using namespace f2q;
+
+struct Emu {
+    RunDev run; PackPlan plan; HostIndex ix; LibDev lib;
+    std::vector<unsigned long long> acc;      // counts + 5 stats
+    EcDev ec; std::vector<unsigned long long> slots, ent_off, ent_count, ent_first, ctr; std::vector<uint32_t> ent_len, arena;
+    uint64_t reads_seen = 0, fast = 0, general = 0;
+    std::string err;
+};
+
+static void bind_lib(Emu *e)
+{
+    LibDev &L = e->lib;
+    L.n_features = e->ix.n_features; L.n_irregular = e->ix.n_irregular;
+    L.tab_keys = e->ix.tab_keys.data(); L.tab_idx = e->ix.tab_idx.data();
+    L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
+    memcpy(L.grp, e->ix.grp, sizeof L.grp);
+    e->acc.assign(e->ix.n_features + 5, 0);
+}
+
+extern "C" {
+
+void *emu_create(const f2q_params *p)
+{
+    Emu *e = new Emu();
+    if (fill_run(*p, e->run, e->err)) { delete e; return nullptr; }
+    e->plan = make_plan(e->run);
+    uint32_t z = 0;
+    build_index(e->ix, "", &z, 0, e->run.miss);
+    bind_lib(e);
+    const size_t cap = 1 << 16, slots = 1 << 18;
+    e->slots.assign(slots, 0); e->ent_off.assign(cap, 0); e->ent_len.assign(cap, 0); e->ent_count.assign(cap, 0);
+    e->ent_first.assign(cap, ~0ull); e->arena.assign(1 << 20, 0); e->ctr.assign(4, 0);
+    e->ec.slots = e->slots.data(); e->ec.mask = slots - 1; e->ec.max_entries = cap; e->ec.ent_off = e->ent_off.data();
+    e->ec.ent_len = e->ent_len.data(); e->ec.ent_count = e->ent_count.data(); e->ec.ent_first = e->ent_first.data();
+    e->ec.arena = e->arena.data(); e->ec.arena_words = e->arena.size(); e->ec.ctr = e->ctr.data();
+    return e;
+}
+void emu_destroy(void *h) { delete (Emu *)h; }
+
+void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t n)
+{
+    Emu *e = (Emu *)h;
+    build_index(e->ix, seqs, offs, n, e->run.miss);
+    bind_lib(e);
+}
+
+// the same two-stream split the library does: packed tiles through fixed_lane, the rest through general_read
+size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
+{
+    Emu *e = (Emu *)h;
+    std::vector<Rec> recs;
+    size_t used = frame_fastq(buf, n, recs);
+    HostPacked hp;
+    pack_records(e->plan, recs, hp);
+    Accum acc{e->acc.data(), e->acc.data() + e->ix.n_features};
+    PackedBlock pb{};
+    pb.n_tiles = hp.n_tiles; pb.wb = hp.wb; pb.wq = hp.wq; pb.rmax = hp.rmax; pb.n_slots = (uint64_t)hp.n_tiles * F2Q_TILE;
+    pb.bases = hp.bases.data(); pb.qual = hp.qual.data(); pb.len = hp.len.data();
+    for (uint32_t t = 0; t < hp.n_tiles; t++)
+        for (uint32_t lane = 0; lane < F2Q_TILE; lane++) {
+            uint32_t idx = 0;
+            int res = fixed_lane(e->run, e->lib, pb, t, lane, idx);
+            if (res == 1 || res == 2) acc.counts[idx]++;
+            if (res) { acc.stats[0]++; acc.stats[res]++; }
+        }
+    for (size_t g = 0; g < hp.g_len.size(); g++) {
+        const uint8_t *seq = hp.raw.data() + hp.g_off[g];
+        general_read(e->run, e->lib, e->ec, acc, seq, (int)hp.g_len[g], seq + hp.g_len[g], (int)hp.g_qlen[g],
+                     e->reads_seen + hp.g_index[g], acc.stats);
+    }
+    e->reads_seen += recs.size(); e->fast += hp.n_clean; e->general += hp.g_len.size();
+    return used;
+}
+
+void emu_read_counts(void *h, int64_t *counts, int64_t *stats, uint64_t *fast, uint64_t *general)
+{
+    Emu *e = (Emu *)h;
+    for (uint32_t i = 0; i < e->ix.n_features; i++) counts[i] = (int64_t)e->acc[i];
+    for (int k = 0; k < 5; k++) stats[k] = (int64_t)e->acc[e->ix.n_features + k];
+    if (fast) *fast = e->fast;
+    if (general) *general = e->general;
+}
+
+uint64_t emu_ec_n(void *h) { return ((Emu *)h)->ctr[0]; }
+uint64_t emu_ec_overflow(void *h) { return ((Emu *)h)->ctr[2]; }
+void emu_ec_get(void *h, uint64_t e_, char *key, uint32_t *len, int64_t *count, uint64_t *first)
+{
+    Emu *e = (Emu *)h;
+    *len = e->ent_len[e_]; *count = (int64_t)e->ent_count[e_]; *first = e->ent_first[e_];
+    memcpy(key, (const uint8_t *)(e->arena.data() + e->ent_off[e_]), *len);
+}
+
+// host twin of the synthetic generator (same code the library's f2q_synth_fastq runs)
+size_t emu_synth_fastq(void *h, const f2q_synth *s, uint64_t lo, uint64_t hi, uint8_t *buf)
+{
+    Emu *e = (Emu *)h;
+    SynthDev d; memset(&d, 0, sizeof d);
+    d.seed = s->seed; d.n_reads = s->n_reads; d.first_read = s->first_read; d.read_len = s->read_len; d.start = s->start;
+    d.cassette = s->cassette; d.max_offset = s->max_offset; d.glen = (int)(e->ix.feat_off[1] - e->ix.feat_off[0]);
+    d.n_guides = (int)e->ix.n_features;
+    d.t_sub = s->t_sub; d.t_rand = s->t_rand; d.t_n = s->t_n; d.t_lowq = s->t_lowq; d.t_q29 = s->t_q29; d.t_q28 = s->t_q28;
+    if (s->cassette) { d.up_len = (int)strlen(s->up); d.down_len = (int)strlen(s->down); memcpy(d.up, s->up, d.up_len); memcpy(d.down, s->down, d.down_len); }
+    const int R = d.read_len; size_t o = 0;
+    const uint64_t *keys = e->ix.key2.data();
+    for (uint64_t i = lo; i < hi; i++) {
+        SynthRead r = synth_plan(d, i, [&](uint32_t g) { return keys[g]; });
+        o += (size_t)sprintf((char *)buf + o, "@r%llu\n", (unsigned long long)i);
+        uint64_t fw = 0;
+        for (int p = 0; p < R; p++) { if ((p & 31) == 0) fw = rnd(d.seed, i, F_FLANK0 + (p >> 5)); buf[o + p] = synth_base(d, r, p, fw); }
+        o += R; buf[o++] = '\n'; buf[o++] = '+'; buf[o++] = '\n';
+        for (int p = 0; p < R; p++) buf[o + p] = (p == r.qpos) ? r.qchar : (uint8_t)'I';
+        o += R; buf[o++] = '\n';
+    }
+    return o;
+}
+
+} // extern "C"

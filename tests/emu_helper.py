@@ -1,0 +1,106 @@
+"""tests/emu_helper.py -- builds and drives tests/emu/libf2q_emu.so: the product's per-lane device
+logic compiled for the host (g++), used by the CPU test-suite to check that logic against the
+oracle and the golden vectors without a GPU.  Test infrastructure only."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "emu", "f2q_emu.cpp")
+LIB = os.path.join(HERE, "emu", "libf2q_emu.so")
+CSRC = os.path.join(os.path.dirname(HERE), "2fast2q_amd", "csrc")
+binding = importlib.import_module("2fast2q_amd.binding")
+
+
+def build():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("f2q_device.h", "f2q_host.h", "f2q_synth.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+                               "-o", LIB, SRC])
+    return LIB
+
+
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        L = C.CDLL(build())
+        vp = C.c_void_p
+        L.emu_create.restype = vp
+        L.emu_create.argtypes = [C.POINTER(binding.Params)]
+        L.emu_destroy.argtypes = [vp]
+        L.emu_set_features.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32), C.c_uint32]
+        L.emu_count_block.restype = C.c_size_t
+        L.emu_count_block.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.emu_read_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64)]
+        L.emu_ec_n.restype = C.c_uint64
+        L.emu_ec_n.argtypes = [vp]
+        L.emu_ec_overflow.restype = C.c_uint64
+        L.emu_ec_overflow.argtypes = [vp]
+        L.emu_ec_get.argtypes = [vp, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_uint64)]
+        L.emu_synth_fastq.restype = C.c_size_t
+        L.emu_synth_fastq.argtypes = [vp, C.POINTER(binding.Synth), C.c_uint64, C.c_uint64, C.c_char_p]
+        _L = L
+    return _L
+
+
+class Emu:
+    def __init__(self, features=None, **params):
+        self._p, self._keep = binding.make_params(**params)
+        self._h = C.c_void_p(lib().emu_create(C.byref(self._p)))
+        if not self._h:
+            raise ValueError("emu_create failed")
+        self.n = 0
+        if features is not None:
+            enc = [s.encode("latin-1") for s in features]
+            offs = np.zeros(len(enc) + 1, dtype=np.uint32)
+            if enc:
+                offs[1:] = np.cumsum([len(b) for b in enc])
+            lib().emu_set_features(self._h, b"".join(enc), offs.ctypes.data_as(C.POINTER(C.c_uint32)), len(enc))
+            self.n = len(enc)
+
+    def count_block(self, data):
+        return lib().emu_count_block(self._h, data, len(data))
+
+    def read(self):
+        counts = (C.c_int64 * max(self.n, 1))()
+        stats = (C.c_int64 * 5)()
+        fast, gen = C.c_uint64(), C.c_uint64()
+        lib().emu_read_counts(self._h, counts, stats, C.byref(fast), C.byref(gen))
+        return list(counts)[:self.n], list(stats), fast.value, gen.value
+
+    def ec_rows(self):
+        L = lib()
+        assert L.emu_ec_overflow(self._h) == 0
+        rows = []
+        for e in range(L.emu_ec_n(self._h)):
+            key = C.create_string_buffer(4096)
+            ln, cnt, first = C.c_uint32(), C.c_int64(), C.c_uint64()
+            L.emu_ec_get(self._h, e, key, C.byref(ln), C.byref(cnt), C.byref(first))
+            rows.append((key.raw[:ln.value].decode("latin-1"), cnt.value, first.value))
+        rows.sort(key=lambda r: r[2])
+        return rows
+
+    def synth_fastq(self, lo, hi, **spec):
+        s, keep = binding.make_synth(**spec)
+        buf = C.create_string_buffer((hi - lo) * (2 * s.read_len + 40) + 64)
+        n = lib().emu_synth_fastq(self._h, C.byref(s), lo, hi, buf)
+        return buf.raw[:n]
+
+    def close(self):
+        if self._h:
+            lib().emu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

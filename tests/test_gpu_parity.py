@@ -1,0 +1,122 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libf2q_hip.so) against the golden vectors
+captured from the reference, and against the oracle on seeded synthetic inputs.  Bit-exact."""
+import pytest
+
+import synth
+from conftest import case_fastq, load_cases, loader_view, pkg
+from oracle import oracle as O
+from test_lane_logic_cpu import params_of
+
+pytestmark = pytest.mark.gpu
+CASES = load_cases()
+
+
+@pytest.fixture(scope="module")
+def P():
+    return pkg()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_golden_case(P, case):
+    feats = loader_view(case["features"]) if case["features"] is not None else None
+    data = case_fastq(case)
+    exp = case["expected"]
+    with P.Counter(features=[s for _, s in feats] if feats is not None else None, **params_of(case)) as c:
+        used = c.count_block(data)
+        counts, stats = c.read_counts()
+        assert list(stats) == exp["stats"]
+        if feats is not None:
+            assert list(counts) == [r[2] for r in exp["rows"]]
+        else:
+            assert [(k, n) for k, n, _ in c.ec_results()] == [(r[1], r[2]) for r in exp["rows"]]
+        # streaming the same buffer in record-aligned pieces accumulates to the same result
+        if len(data) > 200 and case["name"].startswith("synth_fixed_m"):
+            c.reset()
+            for piece in O.split_fastq_on_records(data, 5):
+                assert c.count_block(piece) == len(piece)
+            counts2, stats2 = c.read_counts()
+            assert list(stats2) == exp["stats"] and list(counts2) == [r[2] for r in exp["rows"]]
+
+
+@pytest.mark.parametrize("miss", [0, 1, 2, 3])
+@pytest.mark.parametrize("glen,n_guides,n_reads", [(20, 1000, 200000), (20, 30000, 100000), (12, 3000, 50000), (31, 500, 30000)])
+def test_device_synth_vs_oracle(P, miss, glen, n_guides, n_reads):
+    """device-generated resident block == host FASTQ of the same spec == oracle"""
+    guides = P.binding.synth_library(0xF2A5 + glen, n_guides, glen)
+    assert guides[:20] == synth.make_library(20, glen, 0xF2A5 + glen)
+    spec = dict(seed=100 + miss, n_reads=n_reads, read_len=150, start=3)
+    kw = dict(miss=miss, length=glen, start="3")
+    with P.Counter(features=guides, **kw) as c:
+        fq = bytes(c.synth_fastq(**spec))
+        assert fq[:4000] == synth.make_fastq(synth.Spec(**spec), guides, 0, 40)[:4000]
+        orc = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(guides)], **kw)
+        c.count_block(fq)
+        counts, stats = c.read_counts()
+        assert list(stats) == orc.stats()
+        assert list(counts) == orc.counts()
+        c.reset()
+        blk = c.synth_create(**spec)
+        info = blk.info()
+        assert info["n_reads"] == n_reads
+        t = c.count_resident(blk)
+        counts2, stats2 = c.read_counts()
+        assert list(stats2) == orc.stats() and list(counts2) == orc.counts()
+        assert t["reads"] == n_reads and t["general_reads"] == info["n_general"]
+        # idempotence of accumulation: a second pass doubles everything
+        c.count_resident(blk)
+        counts3, stats3 = c.read_counts()
+        assert list(stats3) == [2 * v for v in orc.stats()] and list(counts3) == [2 * v for v in orc.counts()]
+
+
+def test_anchored_device_synth_vs_oracle(P):
+    up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+    guides = P.binding.synth_library(0xF2A5 + 5, 2000, 20)
+    spec = dict(seed=55, n_reads=60000, read_len=150, cassette=True, up=up, down=down, max_offset=100)
+    for mode in ("C", "EC"):
+        kw = dict(mode=mode, miss=1, upstream=up, downstream=down, miss_search_up=1, miss_search_down=1)
+        with P.Counter(features=guides, miss=1) as gen:
+            fq = bytes(gen.synth_fastq(**spec))
+        feats = [(str(i), s) for i, s in enumerate(guides)] if mode == "C" else None
+        orc = O.Oracle(features=feats, **kw)
+        orc.count_fastq(fq)
+        with P.Counter(features=guides if mode == "C" else None, **kw) as c:
+            c.count_block(fq)
+            counts, stats = c.read_counts()
+            assert list(stats) == orc.stats()
+            if mode == "C":
+                assert list(counts) == orc.counts()
+            else:
+                assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+
+
+def test_full_size_invariants(P):
+    """BASELINE config 2 at full size (10M reads, 1k guides, m=0): size-independent properties."""
+    guides = P.binding.synth_library(0xF2A5 + 2, 1000, 20)
+    n = 10_000_000
+    with P.Counter(features=guides, miss=0) as c:
+        blk = c.synth_create(seed=2, n_reads=n)
+        c.count_resident(blk)
+        counts, stats = c.read_counts()
+        assert stats[0] == n and stats[0] == stats[1] + stats[2] + stats[3] + stats[4]
+        assert counts.sum() == stats[1] + stats[2] and stats[2] == 0
+        # shard-sum invariance: 4 shards of the same stream == the whole
+        blk.free()
+        c.reset()
+        for s in range(4):
+            b = c.synth_create(seed=2, n_reads=n // 4, first_read=s * (n // 4))
+            c.count_resident(b)
+            b.free()
+        counts2, stats2 = c.read_counts()
+        assert list(stats2) == list(stats) and (counts2 == counts).all()
+
+
+def test_error_paths(P):
+    with P.Counter(miss=1) as c:                       # Counter mode without a library
+        with pytest.raises(P.F2QError):
+            c.count_block(b"@r\nACGT\n+\nIIII\n")
+    with pytest.raises(P.F2QError):
+        P.Counter(upstream="ACGT,ACGT", downstream="ACGT")      # unpaired anchors (fast2q.py:553-556)
+    with P.Counter(features=["ACGT"], length=4) as c:
+        assert c.count_block(b"") == 0
+        assert c.count_block(b"@r\nACGT\n+\n") == 0            # partial record: nothing consumed
+        assert list(c.read_counts()[1]) == [0, 0, 0, 0, 0]

@@ -1,0 +1,73 @@
+"""The product's device logic (2fast2q_amd/csrc/f2q_device.h + f2q_host.h) executed lane by lane
+on the host (tests/emu) against the golden vectors captured from the reference and against the
+oracle.  These are the same functions the HIP kernels call per lane; the GPU parity tests
+(test_gpu_parity.py) check the kernels themselves."""
+import pytest
+
+import synth
+from conftest import case_fastq, load_cases, loader_view
+from emu_helper import Emu
+from oracle import oracle as O
+
+CASES = load_cases()
+
+
+def params_of(case):
+    p = case["params"]
+    return dict(mode=p.get("Running Mode", "C"), miss=p.get("miss", 1), phred=p.get("phred", 30),
+                length=p.get("length", 20), start=p.get("start", "0"), upstream=p.get("upstream"),
+                downstream=p.get("downstream"), miss_search_up=p.get("miss_search_up", 0),
+                miss_search_down=p.get("miss_search_down", 0), qual_up=p.get("qual_up", 30),
+                qual_down=p.get("qual_down", 30))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_lane_logic_matches_reference(case):
+    feats = loader_view(case["features"]) if case["features"] is not None else None
+    e = Emu(features=[s for _, s in feats] if feats is not None else None, **params_of(case))
+    e.count_block(case_fastq(case))
+    counts, stats, fast, gen = e.read()
+    exp = case["expected"]
+    assert stats == exp["stats"]
+    if feats is not None:
+        assert counts == [r[2] for r in exp["rows"]]
+    else:
+        rows = e.ec_rows()
+        assert [(k, c) for k, c, _ in rows] == [(r[1], r[2]) for r in exp["rows"]]
+
+
+def test_fast_path_is_exercised():
+    # the synthetic fixed-offset cases must go through the packed fast lane, not the general one
+    case = next(c for c in CASES if c["name"] == "synth_fixed_m1")
+    feats = loader_view(case["features"])
+    e = Emu(features=[s for _, s in feats], **params_of(case))
+    e.count_block(case_fastq(case))
+    _, stats, fast, gen = e.read()
+    assert fast > 0.98 * stats[0] and gen < 0.02 * stats[0] and gen > 0   # reads with 'N' in the window
+
+
+def test_host_generator_matches_spec():
+    guides = synth.make_library(50, 20, 99)
+    for kw in (dict(seed=3, n_reads=300), dict(seed=4, n_reads=300, start=17, read_len=61),
+               dict(seed=5, n_reads=300, cassette=True, up="GTTTAAGAGCTA", down="CGTTACCAGGTT", max_offset=100),
+               dict(seed=6, n_reads=200, cassette=True, up="ACGTACGT", down="TTGGCCAA", max_offset=130, p_n=0.3)):
+        e = Emu(features=guides)
+        assert e.synth_fastq(0, kw["n_reads"], **kw) == synth.make_fastq(synth.Spec(**kw), guides)
+        assert e.synth_fastq(17, 23, **kw) == synth.make_fastq(synth.Spec(**kw), guides, 17, 23)
+
+
+@pytest.mark.parametrize("miss", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("glen,n_guides", [(20, 500), (9, 300), (31, 200), (3, 40), (1, 4)])
+def test_pigeonhole_vs_oracle_dense(miss, glen, n_guides):
+    # dense random libraries + heavy mutation so that ties and multi-piece duplicates are common
+    n_guides = min(n_guides, 4 ** glen)
+    guides = synth.make_library(n_guides, glen, 1000 + glen)
+    spec = synth.Spec(seed=glen * 7 + miss, n_reads=1500, read_len=glen + 9, start=4, p_sub=0.45, p_rand=0.25, p_n=0.05)
+    fq = synth.make_fastq(spec, guides)
+    kw = dict(miss=miss, length=glen, start="4")
+    o = O.Oracle(features=[(f"g{i}", s) for i, s in enumerate(guides)], **kw)
+    o.count_fastq(fq)
+    e = Emu(features=guides, **kw)
+    e.count_block(fq)
+    counts, stats, _, _ = e.read()
+    assert stats == o.stats() and counts == o.counts()
