@@ -18,7 +18,7 @@ EXPORTS = (
     "f2q_version", "f2q_create", "f2q_destroy", "f2q_last_error", "f2q_set_features", "f2q_count_block",
     "f2q_count_file", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
     "f2q_block_free", "f2q_synth_fastq", "f2q_synth_library", "f2q_reset_counts", "f2q_read_counts",
-    "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch",
+    "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base",
 )
 
 ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "EHIP", -4: "ENOMEM", -5: "EIO", -6: "ETRUNCATED", -7: "ESTATE",
@@ -141,6 +141,7 @@ def load(path=None):
     L.f2q_synth_fastq.argtypes = [vp, C.POINTER(Synth), C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_size_t)]
     L.f2q_synth_library.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p]
     L.f2q_reset_counts.argtypes = [vp]
+    L.f2q_set_read_base.argtypes = [vp, C.c_uint64]
     L.f2q_read_counts.argtypes = [vp, i64p, i64p]
     L.f2q_counts_device_ptr.argtypes = [vp, C.POINTER(vp), u64p]
     L.f2q_stream.argtypes = [vp]; L.f2q_stream.restype = vp
@@ -287,6 +288,9 @@ class Counter:
         t = Timing()
         self._check(self._L.f2q_count_resident(self._h, block._h, C.byref(t)))
         return t.as_dict()
+
+    def set_read_base(self, first_read_index):
+        self._check(self._L.f2q_set_read_base(self._h, int(first_read_index)))
 
     # -- results --
     def reset(self):

@@ -417,6 +417,13 @@ extern "C" int f2q_reset_counts(f2q_ctx *c)
     return F2Q_OK;
 }
 
+extern "C" int f2q_set_read_base(f2q_ctx *c, uint64_t first_read_index)
+{
+    if (!c) return F2Q_EINVAL;
+    c->reads_seen = first_read_index;
+    return F2Q_OK;
+}
+
 extern "C" int f2q_read_counts(f2q_ctx *c, int64_t *counts, int64_t stats[5])
 {
     if (!c) return F2Q_EINVAL;

@@ -1,0 +1,503 @@
+"""Host harness of the MI355X-native 2FAST2Q counting path.
+
+This module mirrors the reference's interface for the path (afombravo/2FAST2Q v2.8.1,
+fast2q/fast2q.py) -- same function names, argument meaning, return shapes, output files -- so that
+an existing ``2fast2q -c ...`` command line, features CSV and ``compiled.csv`` consumer keep working:
+
+    features_loader (:125)   reads_counter (:514, the drop-in seam)   aligner (:752)
+    csv_writer (:803)        compiling (:1316)   run_stats (:1386)    input_parser (:1171)
+    initializer (:1082)      file_sizer_split (:1657)   main (:1691)
+
+What is different: reads_counter() does no per-read work in Python.  It hands the file to
+libf2q_hip.so (include/f2q.h) through ctypes; FASTQ framing, Phred masking, window / anchored
+extraction, <= m mismatch matching and count accumulation all run in the library (HIP kernels on
+gfx950).  The reference's Numba helpers, multiprocessing pools, memo caches and chunk splitter
+have no counterpart here (--cp / --fs are accepted and ignored).  There is no CPU fallback: without
+the library or a GPU, reads_counter raises.
+
+Multi-GPU: when launched with one process per GPU (torchrun; RANK/WORLD_SIZE set) every rank
+counts its share of each file's record blocks and the int64 count vector is summed with one
+all-reduce (sharding.py).
+"""
+import argparse
+import csv
+import datetime
+import glob
+import os
+import sys
+import time
+from dataclasses import dataclass
+from pathlib import Path
+
+from . import binding, sharding
+
+version = "2.8.1+mi355x.0.1"
+
+
+@dataclass
+class Features:
+    """name / read count of one feature; instances live in a dict keyed by sequence (:21-44)"""
+    name: str
+    counts: int
+
+
+def colourful_errors(warning_type, error):
+    """timestamped INFO / WARNING / FATAL line (:46-67); no colour codes (colorama is optional upstream only)"""
+    print(f" {datetime.datetime.now().strftime('%c')} [{warning_type}] {error}")
+
+
+def path_finder(folder_path, extension):
+    found = []
+    for ext in extension:
+        for filename in glob.glob(os.path.join(folder_path, ext)):
+            found.append([filename, os.path.getsize(filename)])
+    return found
+
+
+def path_parser(folder_path, extension):
+    """files of the given patterns, by size; the *reads.csv temporaries by name (:91-123)"""
+    pathing = path_finder(folder_path, extension)
+    if extension != ['*reads.csv']:
+        ordered = sorted(pathing, key=lambda e: e[-1])
+        if not ordered:
+            colourful_errors("FATAL", f"Check the path to the {extension} files folder. No files of this type found.\n")
+            sys.exit()
+        return ordered
+    return [p[0] for p in sorted(pathing)]
+
+
+def features_loader(guides):
+    """{SEQUENCE: Features(name, 0)} from a 2-column csv (:125-186): separators ',' ';' tab are tried in
+    turn; sequences are upper-cased with blanks removed; a repeated sequence keeps its first name."""
+    colourful_errors("INFO", "Loading Features")
+    if not os.path.isfile(guides):
+        colourful_errors("FATAL", f"Check the path to the features file.\nNo .csv file found in the following path: {guides}\n")
+        sys.exit()
+    features = {}
+    for sep in (",", ";", "\t"):
+        names = set()
+        try:
+            with open(guides) as handle:
+                for line in handle:
+                    cols = line.rstrip().split(sep)
+                    sequence = cols[1].upper().replace(" ", "")
+                    name = cols[0]
+                    if name in names:
+                        colourful_errors("WARNING", f"The name {name} seems to appear at least twice. This MIGHT result in unexpected behaviour. Please have only unique name entries in your features.csv file.")
+                    if sequence not in features:
+                        features[sequence] = Features(name, 0)
+                        names.add(name)
+                    else:
+                        colourful_errors("WARNING", f"{features[sequence].name} and {name} share the same sequence. Only {features[sequence].name} will be considered valid. {name} will be ignored.")
+        except IndexError:
+            pass
+    if not features:
+        colourful_errors("FATAL", "The given .csv file doesn't seem to be comma, semicolon, or tab separated. Please double check that the file's column separation\n")
+        sys.exit()
+    colourful_errors("INFO", f"{len(features)} different features were provided.")
+    return features
+
+
+def _counter_kwargs(param):
+    return dict(mode=param['Running Mode'], miss=param['miss'], phred=param['phred'], length=param['length'],
+                start=param['start'], upstream=param['upstream'], downstream=param['downstream'],
+                miss_search_up=param['miss_search_up'], miss_search_down=param['miss_search_down'],
+                qual_up=param['qual_up'], qual_down=param['qual_down'],
+                device=int(param.get('device', os.environ.get("LOCAL_RANK", 0))))
+
+
+def reads_counter(i, raw, features, param, reads_stats, preprocess=False):
+    """Counts one FASTQ(.gz) file (:514-582).  Returns (features, reads_stats, local_read_stats), or None
+    for a corrupted gzip -- the reference's contract.  `features` is updated in place: Counter mode adds
+    to Features.counts, Extract+Count mode adds the de-novo keys in first-occurrence order."""
+    if (param['upstream'] is not None) and (param['downstream'] is not None):
+        if len(str(param['upstream']).split(",")) != len(str(param['downstream']).split(",")):
+            colourful_errors("FATAL", "Up and Downstream sequences must be submitted in concurrent pairs, separated by ,.")
+            sys.exit()
+    local_read_stats = dict.fromkeys(binding.STAT_NAMES, 0)
+    if preprocess:                                  # memo warm-up (:1593-1617) has nothing to warm here
+        return features, reads_stats, local_read_stats
+    counter_mode = param['Running Mode'] == 'C'
+    seqs = list(features) if counter_mode else None
+    with binding.Counter(features=seqs, **_counter_kwargs(param)) as ctx:
+        world = sharding.world()
+        if world.size > 1:
+            truncated = sharding.count_file_sharded(ctx, raw, world)
+            counts, stats, ec_rows = sharding.reduce_results(ctx, world)
+        else:
+            _, truncated = ctx.count_file(raw)
+            counts, stats = ctx.read_counts()
+            ec_rows = None if counter_mode else ctx.ec_results()
+    if truncated:
+        colourful_errors("WARNING", f"{raw} is an incomplete or corrupted gzip file. Only partial processing might have occurred.")
+    if counter_mode:
+        for seq, n in zip(seqs, counts):
+            features[seq].counts += int(n)
+    else:
+        for key, n, _first in ec_rows:
+            if key in features:
+                features[key].counts += n
+            else:
+                features[key] = Features(key, n)
+    for k, v in zip(binding.STAT_NAMES, stats):
+        local_read_stats[k] = int(v)
+    return features, reads_stats, local_read_stats
+
+
+def aligner(i, raw, features, param, reads_stats):
+    """one sample: count, then write <sample>_reads.csv (:752-801)"""
+    tempo = time.perf_counter()
+    packed = reads_counter(i, raw, features, param, reads_stats)
+    if packed is None:
+        return reads_stats
+    features, reads_stats, local = packed
+    master_list = [[features[g].name, features[g].counts] for g in features]
+    tempo = time.perf_counter() - tempo
+    if tempo > 3600:
+        timing = str(round(tempo / 3600, 2)) + " hours"
+    elif tempo > 60:
+        timing = str(round(tempo / 60, 2)) + " minutes"
+    else:
+        timing = str(round(tempo, 2)) + " seconds"
+    name = Path(raw).stem
+    if ".fastq" in name:
+        name = Path(name).stem
+    stats_condition = (f'#script ran in {timing} for file {name}. '
+                       f'{local["perfect_counter"] + local["imperfect_counter"]} reads out of {local["reads"]} were aligned. '
+                       f'{local["perfect_counter"]} were perfectly aligned. '
+                       f'{local["imperfect_counter"]} were aligned with mismatch. '
+                       f'{local["non_aligned_counter"]} passed quality filtering but were not aligned. '
+                       f'{local["quality_failed"]} did not pass quality filtering.')
+    if not param['Progress bar']:
+        colourful_errors("INFO", f"Sample {name} was processed in {timing}")
+    try:
+        master_list.sort(key=lambda row: int(row[0]))
+    except ValueError:
+        master_list.sort(key=lambda row: row[0])
+    master_list.insert(0, ["#Feature", "Reads"])
+    master_list.insert(0, [stats_condition])
+    if sharding.world().rank == 0:
+        csv_writer(os.path.join(param["directory"], name + "_reads.csv"), master_list)
+    return reads_stats
+
+
+def csv_writer(path, outfile):
+    """csv.writer rows (CRLF line ends, like the reference :803-809)"""
+    with open(path, "w", newline='') as output:
+        csv.writer(output).writerows(outfile)
+
+
+def initializer(cmd):
+    """banner-less counterpart of :1082-1169: coerces the Phred inputs, creates the output directory name"""
+    param = cmd
+    if param is None:
+        colourful_errors("FATAL", "Only the command line mode (-c) is provided by this build; the tkinter dialog of the reference is not.")
+        sys.exit(2)
+    print(f"\n 2FAST2Q (MI355X counting path)  Version: {version}")
+    if param["test_mode"]:
+        colourful_errors("WARNING", "Running test mode!\n")
+    param["version"] = version
+    for key in ("phred", "qual_up", "qual_down"):
+        if int(param[key]) <= 0:            # :1118-1125
+            param[key] = 1
+    current_time = datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')
+    param["directory"] = os.path.join(param['out'], f"2FAST2Q_output_{current_time}")
+    print("\n -- Parameters -- ")
+    if param['Running Mode'] == 'C':
+        print("\n Mode: Align and count")
+        print(f" Allowed mismatches per alignement: {param['miss']}")
+    else:
+        print("\n Mode: Extract and count")
+    print(f" Minimal Phred Score per bp >= {param['phred']}")
+    if param['upstream'] is not None:
+        print(f" Upstream search sequence: {param['upstream']}")
+        print(f" Mismatches allowed in the upstream search sequence: {param['miss_search_up']}")
+        print(f" Minimal Phred-score in the upstream search sequence: {param['qual_up']}")
+    if param['downstream'] is not None:
+        print(f" Downstream search sequence: {param['downstream']}")
+        print(f" Mismatches allowed in the downstream search sequence: {param['miss_search_down']}")
+        print(f" Minimal Phred-score in the downstream search sequence: {param['qual_down']}")
+    if (param['upstream'] is None) or (param['downstream'] is None):
+        print(f" Finding features with the folowing length: {param['length']}bp")
+    if (param['upstream'] is None) and (param['downstream'] is None):
+        print(f" Read alignment start position: {param['start']}")
+    print(f" All data will be saved into {param['directory']}")
+    print("\n ---- ")
+    param["cpu"] = param["cpu"] if isinstance(param["cpu"], int) and param["cpu"] > 0 else (os.cpu_count() or 1)
+    return param
+
+
+def _package_data(name):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name)
+
+
+def ensure_example_fastq():
+    """The upstream demo FASTQ is not redistributed (.MISSING_LARGE_BLOBS); test mode synthesises a
+    stand-in of 20,000 reads from the packaged D39V library with the §8(d) generator."""
+    import gzip
+    path = _package_data("example.fastq.gz")
+    if os.path.exists(path):
+        return path
+    feats = {}
+    with open(_package_data("D39V_guides.csv")) as h:
+        for line in h:
+            cols = line.rstrip().split(",")
+            feats.setdefault(cols[1].upper().replace(" ", ""), cols[0])
+    with binding.Counter(features=list(feats), miss=1) as ctx:
+        fq = bytes(ctx.synth_fastq(seed=0xD39, n_reads=20000, read_len=75))
+    try:
+        with gzip.open(path, "wb", compresslevel=6) as f:
+            f.write(fq)
+    except OSError:
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(prefix="f2q_demo_"), "example.fastq.gz")
+        with gzip.open(path, "wb", compresslevel=6) as f:
+            f.write(fq)
+    return path
+
+
+def input_parser(argv=None):
+    """the reference's flag set (:1193-1216) and defaults (:1246-1309), plus --gpu (device ordinal)"""
+    ap = argparse.ArgumentParser(prog="2fast2q")
+    ap.add_argument("-c", nargs='?', const=True, help="cmd line mode.")
+    ap.add_argument("-t", nargs='?', const=True, help="Runs 2FAST2Q in test mode with example data.")
+    ap.add_argument("-v", nargs='?', const=True, help="Prints the current version.")
+    ap.add_argument("--s", help="The full path to the directory with the sequencing files OR file.")
+    ap.add_argument("--g", help="The full path to the .csv file with the sgRNAs.")
+    ap.add_argument("--o", help="The full path to the output directory")
+    ap.add_argument("--fn", nargs='?', const="compiled", help="Specify an output compiled file name (default is called compiled)")
+    ap.add_argument("--pb", nargs='?', const=False, help="Adds progress bars (default is enabled)")
+    ap.add_argument("--m", help="The number of allowed mismatches per feature (default = 1). Ignored in extract + Count mode.")
+    ap.add_argument("--ph", help="Minimal Phred-score (default=30).")
+    ap.add_argument("--st", help="The start position of the feature within the read (default = 0).")
+    ap.add_argument("--l", help="The length of the feature in bp (default = 20).")
+    ap.add_argument("--us", help="Upstream search sequence.")
+    ap.add_argument("--ds", help="Downstream search sequence.")
+    ap.add_argument("--msu", help="Upstream search sequence mismatches (default is 0).")
+    ap.add_argument("--msd", help="Downstream search sequence mismatches (default is 0).")
+    ap.add_argument("--qsu", help="Minimal Phred-score (default=30) in the upstream search sequence")
+    ap.add_argument("--qsd", help="Minimal Phred-score (default=30) in the downstream search sequence")
+    ap.add_argument("--mo", help="Running Mode (default=C) [Counter (C) / Extractor + Counter (EC)].")
+    ap.add_argument("--cp", help="Number of cpus (accepted for compatibility; the counting runs on the GPU)")
+    ap.add_argument("--fs", nargs='?', const=False, help="File Split mode (accepted for compatibility; ignored)")
+    ap.add_argument("--k", nargs='?', const=False, help="If enabled, keeps all temporary files (default is disabled)")
+    ap.add_argument("--gpu", help="HIP device ordinal (default: LOCAL_RANK or 0)")
+    args = ap.parse_args(argv)
+    if args.v is not None:
+        print(f"\nVersion: {version}\n")
+        sys.exit()
+    if args.c is None:
+        return None
+    p = {"cmd": True, "big_file_split": args.fs is not None}
+    p['used_cmd'] = " ".join(f"--{k}" if isinstance(v, bool) and v else f"--{k} {v}"
+                             for k, v in vars(args).items() if v is not None)
+    p['Running Mode'] = "EC" if (args.mo is not None and "EC" in args.mo.upper()) else "C"
+    if args.t is None:
+        p["test_mode"] = False
+        paths = [[args.s, 'seq_files'], [args.g, 'feature'], [args.o, 'out']]
+    else:
+        p["test_mode"] = True
+        paths = [[ensure_example_fastq(), 'seq_files'], [_package_data('D39V_guides.csv'), 'feature'], [os.getcwd(), 'out']]
+    p['out_file_name'] = args.fn if args.fn is not None else "compiled"
+    p['length'] = int(args.l) if args.l is not None else 20
+    p['Progress bar'] = args.pb is None
+    p['start'] = args.st if args.st is not None else "0"
+    p['phred'] = int(args.ph) if args.ph is not None else 30
+    p['miss'] = int(args.m) if args.m is not None else 1
+    p['upstream'], p['downstream'] = args.us, args.ds
+    p['miss_search_up'] = int(args.msu) if args.msu is not None else 0
+    p['miss_search_down'] = int(args.msd) if args.msd is not None else 0
+    p['qual_up'] = int(args.qsu) if args.qsu is not None else 30
+    p['qual_down'] = int(args.qsd) if args.qsd is not None else 30
+    p['delete'] = args.k is None
+    p['cpu'] = int(args.cp) if args.cp is not None else False
+    if args.gpu is not None:
+        p['device'] = int(args.gpu)
+    for value, key in paths:                                   # :1178-1191
+        if value is None:
+            p[key] = os.getcwd()
+            if key == 'feature':
+                found = path_finder(os.getcwd(), ["*.csv"])
+                if p['Running Mode'] != "EC":
+                    if len(found) > 1:
+                        colourful_errors("FATAL", "There is more than one .csv in the current directory. If not directly indicating a path for the features .csv, please have only 1 .csv file in the directory.\n")
+                        sys.exit()
+                    if len(found) == 1:
+                        p[key] = found[0][0]
+        else:
+            p[key] = value
+    return p
+
+
+def file_sizer_split(param):
+    """sample discovery (:1657-1689): *.gz and *.fastq of the --s directory, smallest first"""
+    if param["test_mode"]:
+        param["sequencing_files"] = {"len_files": 1, "preprocess_files": [param["seq_files"]], "files": [param["seq_files"]]}
+        return param
+    files = [p[0] for p in path_parser(param["seq_files"], ["*.gz", "*.fastq"])]
+    param["sequencing_files"] = {"len_files": len(files), "preprocess_files": files[:1], "files": files}
+    return param
+
+
+def aligner_mp_dispenser(features, param, start=0):
+    """every sample through aligner() (:1619-1655); samples are independent, one GPU pass each"""
+    if sharding.world().rank == 0:
+        os.makedirs(param["directory"], exist_ok=True)
+    sharding.barrier()
+    reads_stats = {"failed_reads": set(), "passed_reads": {}}
+    colourful_errors("INFO", f"Processing {param['sequencing_files']['len_files']} files. Please hold.")
+    for i, raw in enumerate(param['sequencing_files']['files']):
+        # Counter mode: each sample starts from zeroed counts, as the per-process `features` copy does upstream
+        per_sample = {k: Features(v.name, 0) for k, v in features.items()} if param['Running Mode'] == 'C' else {}
+        aligner(i, raw, per_sample, param, reads_stats)
+
+
+def compiling(param):
+    """merge the per-sample *_reads.csv into <name>.csv and the stats file (:1316-1384)"""
+    ordered_csv = path_parser(param["directory"], ['*reads.csv'])
+    headers = [f"#2FAST2Q version: {param['version']}",
+               f"#Mismatch: {param['miss']}",
+               f"#Phred Score: {param['phred']}",
+               f"#Feature Length: {param['length']}",
+               f"#Feature start position in the read: {param['start']}",
+               f"#Running mode: {param['Running Mode']}",
+               f"#Upstream search sequence: {param['upstream']}",
+               f"#Downstream search sequence: {param['downstream']}",
+               f"#Mismatches in the upstream search sequence: {param['miss_search_up']}",
+               f"#Mismatches in the downstream search sequence: {param['miss_search_down']}",
+               f"#Minimal Phred-score in the upstream search sequence: {param['qual_up']}",
+               f"#Minimal Phred-score in the downstream search sequence: {param['qual_down']}"]
+    if "used_cmd" in param:
+        headers.insert(1, f"#cmd used: {param['used_cmd']}")
+    headers.reverse()
+    compiled, head = {}, ["#Feature"]
+    for i, file in enumerate(ordered_csv):
+        sample = Path(os.path.splitext(file)[0]).stem[:-len("_reads")]
+        head.append(sample)
+        with open(file) as current:
+            for line in current:
+                cols = line.rstrip().split(",")
+                if "#" not in cols[0]:
+                    if cols[0] in compiled:
+                        compiled[cols[0]] = compiled[cols[0]] + [int(cols[1])]
+                    else:
+                        compiled[cols[0]] = [0] * i + [int(cols[1])]
+                elif "#Feature" not in cols[0]:
+                    headers.append(cols[0][1:] + "\n")
+        for entry in compiled:                                       # zero back-fill (:1361-1364)
+            if len(compiled[entry]) < i + 1:
+                compiled[entry] = compiled[entry] + [0] * (i + 1 - len(compiled[entry]))
+    run_stats(headers, param, compiled, head)
+    final = [head] + [[feature] + compiled[feature] for feature in compiled]
+    csv_writer(os.path.join(param["directory"], f"{param['out_file_name']}.csv"), final)
+    if param["delete"]:
+        for file in ordered_csv:
+            os.remove(file)
+    colourful_errors("INFO", "Analysis successfully completed")
+    print("\n If you find 2FAST2Q useful, please consider citing:\n Bravo AM, Typas A, Veening J. 2022. \n 2FAST2Q: a general-purpose sequence search and counting program for FASTQ files. PeerJ 10:e14041\n DOI: 10.7717/peerj.14041\n")
+    if param["test_mode"]:
+        colourful_errors("WARNING", "Test successful. 2FAST2Q is working as intended!\n")
+
+
+def run_stats(headers, param, compiled, head):
+    """<name>_stats.csv plus the four overview plots (:1386-1527)"""
+    global_stat = [["#Sample name", "Running Time", "Running Time unit", "Total number of reads in sample",
+                    "Total number of reads that were aligned", "Number of reads that were aligned without mismatches",
+                    "Number of reads that were aligned with mismatches",
+                    "Number of reads that passed quality filtering but were not aligned",
+                    'Number of reads that did not pass quality filtering.']]
+    offset = 1
+    for run in headers:
+        if "script ran" in run:
+            w = run.split()        # the stats sentence written by aligner(); token positions as upstream (:1403-1406)
+            global_stat.append([w[7][:-1], w[3], w[4], w[12], w[8], w[15], w[19], w[24], w[32]])
+        else:
+            global_stat.insert(0, [run])
+            offset += 1
+    csv_writer(os.path.join(param["directory"], f"{param['out_file_name']}_stats.csv"), global_stat)
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        import numpy as np
+    except Exception as exc:                                     # plots are cosmetic; say so and go on
+        colourful_errors("WARNING", f"matplotlib unavailable ({exc}); plots skipped")
+        return
+    rows = global_stat[offset:]
+    base = os.path.join(param["directory"], param['out_file_name'])
+    labels = [r[0] for r in rows]
+
+    def bars(relative, path, xlabel, legend):
+        fig, ax = plt.subplots(figsize=(12, max(1, int(len(global_stat) / 4))))
+        for i, r in enumerate(rows):
+            total, aligned, not_aligned, qfail = int(r[3]), int(r[4]), int(r[7]), int(r[8])
+            if relative:
+                tot = max(total, 1)
+                a, n, q = aligned / tot * 100, not_aligned / tot * 100, qfail / tot * 100
+                ax.barh(i, a, .75, color="#6290C3", hatch="\\", edgecolor="black", linewidth=.7)
+                ax.barh(i, n, .75, left=a, color="#F1FFE7", hatch="//", edgecolor="black", linewidth=.7)
+                ax.barh(i, q, .75, left=a + n, color="#FB5012", hatch="||", edgecolor="black", linewidth=.7)
+            else:
+                ax.barh(i, total, .75, color="#FFD25A", hatch="//", edgecolor="black", linewidth=.7)
+                ax.barh(i, aligned, .75, color="#FFAA5A", hatch="\\", edgecolor="black", linewidth=.7)
+                ax.barh(i, not_aligned, .75, color="#F56416", hatch="x", edgecolor="black", linewidth=.7)
+        ax.set_yticks(np.arange(len(labels)))
+        ax.set_yticklabels(labels)
+        ax.tick_params(axis='both', which='both', labelsize=16)
+        ax.set_xlabel(xlabel, size=20)
+        ax.spines['top'].set_visible(False)
+        ax.spines['right'].set_visible(False)
+        ax.set_xlim(xmin=1)
+        ax.legend(legend, loc='right', bbox_to_anchor=(1.1, 1), ncol=3, prop={'size': 12})
+        fig.tight_layout()
+        fig.savefig(path, dpi=300, bbox_inches='tight')
+        plt.close(fig)
+
+    bars(False, base + "_reads_plot.png", 'Number of reads',
+         ["Total reads in sample", "Aligned reads", "Reads that passed quality filtering but failed to align"])
+    bars(True, base + "_reads_plot_percentage.png", '% of reads per sample',
+         ["Aligned reads", "Reads that passed quality filtering but failed to align", "Reads that did not pass quality filtering"])
+
+    per_sample = [[compiled[f][k] for f in compiled] for k in range(len(head) - 1)]
+
+    def violin(data, path, title):
+        fig, ax = plt.subplots(figsize=(12, max(1.0, len(global_stat) / 2)))
+        ax.set_title(title, size=20)
+        ax.set_xlabel('Reads per feature', size=20)
+        if data and all(len(d) for d in data):
+            parts = ax.violinplot(data, points=200, widths=1, showmeans=False, showmedians=False, showextrema=False, vert=False)
+            for pc in parts['bodies']:
+                pc.set_facecolor('#D43F3A'); pc.set_edgecolor('black'); pc.set_alpha(1)
+            q1, med, q3 = np.percentile(np.array(data, dtype=float), [25, 50, 75], axis=1)
+            inds = np.arange(1, len(med) + 1)
+            ax.scatter(med, inds, marker='o', color='white', s=40, zorder=3)
+            ax.hlines(inds, q1, q3, color='k', linestyle='-', lw=8)
+        ax.set_yticks(np.arange(len(head[1:])) + 1)
+        ax.set_yticklabels(head[1:])
+        ax.tick_params(axis='both', which='major', labelsize=20)
+        ax.spines['top'].set_visible(False)
+        ax.spines['right'].set_visible(False)
+        ax.set_xlim(xmin=1)
+        fig.savefig(path, dpi=300, bbox_inches='tight')
+        plt.close(fig)
+
+    violin(per_sample, base + "_distribution_plot.png", 'Reads per feature distribution')
+    rpm = [[v / sum(d) * 1000000 for v in d] for d in per_sample if sum(d) > 0]
+    violin(rpm if len(rpm) == len(per_sample) else [], base + "_distribution_normalized_RPM_plot.png",
+           'Reads per feature (RPM normalized) distribution')
+
+
+def main(argv=None):
+    param = file_sizer_split(initializer(input_parser(argv)))
+    features = {}
+    if param['Running Mode'] == 'C':
+        features = features_loader(param["feature"])
+    aligner_mp_dispenser(features, param)
+    sharding.barrier()
+    if sharding.world().rank == 0:
+        compiling(param)
+    sharding.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,10 @@ int f2q_synth_fastq(f2q_ctx *ctx, const f2q_synth *spec, uint64_t lo, uint64_t h
 /* n unique uniform ACGT strings of `length` bases (tests/synth.py make_library); out = n*length bytes */
 int f2q_synth_library(uint64_t seed, uint32_t n, uint32_t length, char *out);
 
+/* Global index of the next block's first read (default: running count of reads seen).  Only the
+ * first-occurrence order of Extract+Count keys depends on it; sharded callers set it per block. */
+int f2q_set_read_base(f2q_ctx *ctx, uint64_t first_read_index);
+
 /* ---- results -------------------------------------------------------------------------------- */
 int f2q_reset_counts(f2q_ctx *ctx);
 /* Counter mode: counts[n_features] + stats[5] (device -> host, synchronises the stream). */

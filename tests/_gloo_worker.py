@@ -1,0 +1,30 @@
+"""worker of tests/test_sharding_gloo.py: one rank of a world_size-N gloo job.  The per-rank counting
+engine is tests/emu (the product's lane logic on the host) because this machine has no GPU; the
+sharding / reduction code under test is the product's 2fast2q_amd/sharding.py."""
+import importlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    cfg = json.load(open(sys.argv[1]))
+    os.environ["F2Q_DIST_BACKEND"] = "gloo"
+    sharding = importlib.import_module("2fast2q_amd.sharding")
+    from emu_helper import Emu
+    w = sharding.world()
+    eng = Emu(features=cfg["features"], **cfg["params"])
+    trunc = sharding.count_file_sharded(eng, cfg["path"], w, block_bytes=cfg["block_bytes"])
+    counts, stats, ec = sharding.reduce_results(eng, w)
+    own = eng.read()[1][0]
+    json.dump({"counts": [int(x) for x in counts], "stats": [int(x) for x in stats], "ec": ec, "own_reads": own,
+               "truncated": trunc}, open(f"{cfg['out']}.{w.rank}", "w"))
+    sharding.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,6 +3,7 @@
 // the host, so that the logic the HIP kernels execute can be checked against the oracle on a
 // machine without a GPU.  The product never uses this file; libf2q_hip.so has no host path.
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -97,6 +98,7 @@ void emu_read_counts(void *h, int64_t *counts, int64_t *stats, uint64_t *fast, u
     if (general) *general = e->general;
 }
 
+void emu_set_read_base(void *h, uint64_t b) { ((Emu *)h)->reads_seen = b; }
 uint64_t emu_ec_n(void *h) { return ((Emu *)h)->ctr[0]; }
 uint64_t emu_ec_overflow(void *h) { return ((Emu *)h)->ctr[2]; }
 void emu_ec_get(void *h, uint64_t e_, char *key, uint32_t *len, int64_t *count, uint64_t *first)

@@ -39,6 +39,7 @@ def lib():
         L.emu_count_block.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.emu_read_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64)]
+        L.emu_set_read_base.argtypes = [vp, C.c_uint64]
         L.emu_ec_n.restype = C.c_uint64
         L.emu_ec_n.argtypes = [vp]
         L.emu_ec_overflow.restype = C.c_uint64
@@ -87,6 +88,21 @@ class Emu:
             rows.append((key.raw[:ln.value].decode("latin-1"), cnt.value, first.value))
         rows.sort(key=lambda r: r[2])
         return rows
+
+    # -- the subset of binding.Counter's interface that sharding.py drives --
+    @property
+    def mode(self):
+        return "C" if self._p.mode == 0 else "EC"
+
+    def set_read_base(self, b):
+        lib().emu_set_read_base(self._h, int(b))
+
+    def read_counts(self):
+        counts, stats, _, _ = self.read()
+        return np.array(counts, dtype=np.int64), np.array(stats, dtype=np.int64)
+
+    def ec_results(self):
+        return self.ec_rows()
 
     def synth_fastq(self, lo, hi, **spec):
         s, keep = binding.make_synth(**spec)

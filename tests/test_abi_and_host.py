@@ -1,0 +1,138 @@
+"""CPU-side checks of the boundary: the shared library loads and exports every symbol that
+include/f2q.h declares (no compute calls), the ctypes structs match the C layout, the product has
+no CPU fallback, and the host harness reproduces the reference's file formats."""
+import csv
+import importlib
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, pkg
+
+binding = importlib.import_module("2fast2q_amd.binding")
+fast2q = importlib.import_module("2fast2q_amd.fast2q")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "f2q.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(f2q_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    L = binding.load()
+    declared = header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/f2q.h but not exported"
+    assert sorted(binding.EXPORTS) == declared
+    assert L.f2q_version() == 1
+
+
+def test_struct_layout_matches_c(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "f2q.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(f2q_params),offsetof(f2q_params,upstream),offsetof(f2q_params,device),sizeof(f2q_synth),'
+                   'offsetof(f2q_synth,t_sub),sizeof(f2q_timing));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    import ctypes as C
+    want = [C.sizeof(binding.Params), binding.Params.upstream.offset, binding.Params.device.offset,
+            C.sizeof(binding.Synth), binding.Synth.t_sub.offset, C.sizeof(binding.Timing)]
+    assert got == want
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(binding.F2QError) as e:
+        binding.Counter(features=["ACGT"], length=4)
+    assert e.value.code == -2                     # F2Q_ENODEVICE: the product fails loudly
+
+
+def test_product_does_not_touch_the_oracle():
+    # the oracle is a checker only: nothing under 2fast2q_amd/ may import, load or link it
+    bad = re.compile(r"(import\s+oracle|from\s+oracle|libf2q_oracle|oracle/|f2q_oracle|emu_helper|libf2q_emu)")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "2fast2q_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not bad.search(text), f
+
+
+def test_features_loader_d39v(capsys):
+    feats = fast2q.features_loader(os.path.join(ROOT, "2fast2q_amd", "data", "D39V_guides.csv"))
+    assert len(feats) == 1498                                     # sgRNA0867 duplicates sgRNA0850
+    names = [f.name for f in feats.values()]
+    assert "sgRNA0850" in names and "sgRNA0867" not in names
+    assert all(set(s) <= set("ACGT") and len(s) == 20 for s in feats)       # row 81's trailing blank is gone
+    assert "share the same sequence" in capsys.readouterr().out
+
+
+def test_features_loader_separators(tmp_path):
+    for sep in (",", ";", "\t"):
+        p = tmp_path / "f.csv"
+        p.write_text(f"a{sep}acgt \nb{sep}AC GT\nc{sep}TTTT\n")
+        feats = fast2q.features_loader(str(p))
+        assert list(feats) == ["ACGT", "TTTT"] and feats["ACGT"].name == "a"
+
+
+def test_input_parser_defaults_and_flags():
+    p = fast2q.input_parser(["-c", "--s", "/x", "--g", "/g.csv", "--o", "/o"])
+    assert (p["length"], p["start"], p["phred"], p["miss"], p["Running Mode"]) == (20, "0", 30, 1, "C")
+    assert (p["miss_search_up"], p["miss_search_down"], p["qual_up"], p["qual_down"]) == (0, 0, 30, 30)
+    assert p["upstream"] is None and p["downstream"] is None and p["delete"] and p["Progress bar"]
+    p = fast2q.input_parser(["-c", "--s", "/x", "--o", "/o", "--mo", "ec", "--us", "ACGT", "--ds", "TTTT", "--msu", "1",
+                             "--msd", "2", "--qsu", "20", "--qsd", "10", "--m", "2", "--ph", "25", "--l", "15",
+                             "--st", "3,9", "--k", "--pb", "--fn", "out", "--cp", "4", "--fs"])
+    assert p["Running Mode"] == "EC" and p["upstream"] == "ACGT" and p["downstream"] == "TTTT"
+    assert (p["miss_search_up"], p["miss_search_down"], p["qual_up"], p["qual_down"]) == (1, 2, 20, 10)
+    assert (p["miss"], p["phred"], p["length"], p["start"]) == (2, 25, 15, "3,9")
+    assert not p["delete"] and not p["Progress bar"] and p["out_file_name"] == "out" and p["cpu"] == 4
+    assert fast2q.input_parser([]) is None
+
+
+def _sentence(name, reads, perfect, imperfect, non_aligned, qfail, timing="0.5 seconds"):
+    return (f"#script ran in {timing} for file {name}. {perfect + imperfect} reads out of {reads} were aligned. "
+            f"{perfect} were perfectly aligned. {imperfect} were aligned with mismatch. {non_aligned} passed quality "
+            f"filtering but were not aligned. {qfail} did not pass quality filtering.")
+
+
+def test_compiling_formats(tmp_path):
+    d = tmp_path / "out"
+    d.mkdir()
+    fast2q.csv_writer(str(d / "s1_reads.csv"), [[_sentence("s1", 10, 5, 2, 2, 1)], ["#Feature", "Reads"], ["g1", 4], ["g2", 3]])
+    fast2q.csv_writer(str(d / "s2_reads.csv"), [[_sentence("s2", 20, 9, 1, 6, 4)], ["#Feature", "Reads"], ["g1", 7], ["g3", 3]])
+    param = dict(directory=str(d), version="x", miss=1, phred=30, length=20, start="0", upstream=None, downstream=None,
+                 miss_search_up=0, miss_search_down=0, qual_up=30, qual_down=30, out_file_name="compiled", delete=True,
+                 test_mode=False, used_cmd="--c")
+    param["Running Mode"] = "C"
+    fast2q.compiling(param)
+    files = sorted(os.listdir(d))
+    assert files == ["compiled.csv", "compiled_distribution_normalized_RPM_plot.png", "compiled_distribution_plot.png",
+                     "compiled_reads_plot.png", "compiled_reads_plot_percentage.png", "compiled_stats.csv"]   # 6 files
+    raw = (d / "compiled.csv").read_bytes()
+    assert raw == b"#Feature,s1,s2\r\ng1,4,7\r\ng2,3,0\r\ng3,0,3\r\n"       # CRLF, zero back-fill, first-file order
+    rows = list(csv.reader(open(d / "compiled_stats.csv")))
+    assert rows[-2] == ["s1", "0.5", "seconds", "10", "7", "5", "2", "2", "1"]
+    assert rows[-1] == ["s2", "0.5", "seconds", "20", "10", "9", "1", "6", "4"]
+    assert rows[-3][0] == "#Sample name" and any("#Mismatch: 1" in r[0] for r in rows)
+
+
+def test_reference_golden_compiled_format():
+    # the reference's own tests/compiled.csv pins the format only (its FASTQ is not redistributed):
+    # header '#Feature,<sample>' then one 'name,count' row per unique feature, in library order
+    ref = "/root/reference/tests/compiled.csv"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present on this machine")
+    rows = list(csv.reader(open(ref)))
+    feats = fast2q.features_loader(os.path.join(ROOT, "2fast2q_amd", "data", "D39V_guides.csv"))
+    assert rows[0] == ["#Feature", "example"]
+    assert [r[0] for r in rows[1:]] == sorted(f.name for f in feats.values())
+    assert sum(int(r[1]) for r in rows[1:]) == 60916

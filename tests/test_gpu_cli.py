@@ -1,0 +1,108 @@
+"""GPU: the drop-in surface -- reads_counter() on files, and the `2fast2q -c` command line end to end."""
+import csv
+import gzip
+import importlib
+import os
+
+import pytest
+
+import synth
+from conftest import ROOT, pkg
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+fast2q = importlib.import_module("2fast2q_amd.fast2q")
+
+
+def default_param(**kw):
+    p = {"Running Mode": "C", "miss": 1, "phred": 30, "length": 20, "start": "0", "upstream": None, "downstream": None,
+         "miss_search_up": 0, "miss_search_down": 0, "qual_up": 30, "qual_down": 30, "Progress bar": False,
+         "big_file_split": False}
+    p.update(kw)
+    return p
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_reads_counter_seam(tmp_path, gz):
+    guides = synth.make_library(300, 20, 41)
+    fq = synth.make_fastq(synth.Spec(seed=21, n_reads=5000, read_len=80), guides)
+    path = tmp_path / ("a.fastq.gz" if gz else "a.fastq")
+    (gzip.open(path, "wb") if gz else open(path, "wb")).write(fq)
+    features = {g: fast2q.Features(f"n{i}", 0) for i, g in enumerate(guides)}
+    memo = {"failed_reads": set(), "passed_reads": {}}
+    out = fast2q.reads_counter(0, str(path), features, default_param(), memo)
+    feats, memo2, stats = out
+    orc = O.Oracle(features=[(f"n{i}", g) for i, g in enumerate(guides)], miss=1)
+    orc.count_fastq(fq)
+    assert feats is features and memo2 is memo
+    assert [f.counts for f in feats.values()] == orc.counts()
+    assert stats == orc.stats_dict()
+
+
+def test_reads_counter_extract_count(tmp_path):
+    guides = synth.make_library(100, 20, 42)
+    up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+    fq = synth.make_fastq(synth.Spec(seed=22, n_reads=3000, cassette=True, up=up, down=down), guides)
+    path = tmp_path / "b.fastq"
+    path.write_bytes(fq)
+    kw = dict(upstream=up, downstream=down, miss_search_up=1, miss_search_down=1)
+    feats, _, stats = fast2q.reads_counter(0, str(path), {}, default_param(**{"Running Mode": "EC"}, **kw), {})
+    orc = O.Oracle(mode="EC", **kw)
+    orc.count_fastq(fq)
+    assert [(k, f.name, f.counts) for k, f in feats.items()] == [(k, k, n) for k, n in zip(orc.keys(), orc.counts())]
+    assert stats == orc.stats_dict()
+
+
+def test_truncated_gzip_partial_counts(tmp_path, capsys):
+    guides = synth.make_library(50, 20, 43)
+    fq = synth.make_fastq(synth.Spec(seed=23, n_reads=20000, read_len=60), guides)
+    raw = gzip.compress(fq)
+    path = tmp_path / "t.fastq.gz"
+    path.write_bytes(raw[: len(raw) // 2])
+    features = {g: fast2q.Features(str(i), 0) for i, g in enumerate(guides)}
+    feats, _, stats = fast2q.reads_counter(0, str(path), features, default_param(), {})
+    assert 0 < stats["reads"] < 20000                                # partial processing kept (fast2q.py:405-407)
+    assert "incomplete or corrupted gzip" in capsys.readouterr().out
+
+
+def test_cli_test_mode_end_to_end(tmp_path, monkeypatch):
+    """`2fast2q -c -t` (reference tests/test_cli.py): exit 0, one output folder, exactly 6 files; and -- what
+    upstream leaves commented out -- compiled.csv equals an independent count of the same input."""
+    monkeypatch.chdir(tmp_path)
+    fast2q.main(["-c", "-t", "--pb"])
+    subdirs = [d for d in tmp_path.iterdir() if d.is_dir()]
+    assert len(subdirs) == 1
+    files = sorted(p.name for p in subdirs[0].iterdir())
+    assert len(files) == 6 and "compiled.csv" in files and "compiled_stats.csv" in files
+    feats = fast2q.features_loader(os.path.join(ROOT, "2fast2q_amd", "data", "D39V_guides.csv"))
+    fq = gzip.open(fast2q.ensure_example_fastq()).read()
+    orc = O.Oracle(features=[(f.name, s) for s, f in feats.items()], miss=1)
+    orc.count_fastq(fq)
+    want = sorted(zip(orc.names, orc.counts()))
+    rows = list(csv.reader(open(subdirs[0] / "compiled.csv", newline="")))
+    assert rows[0] == ["#Feature", "example"]
+    assert [(r[0], int(r[1])) for r in rows[1:]] == want
+    stats = list(csv.reader(open(subdirs[0] / "compiled_stats.csv")))[-1]
+    assert [int(x) for x in (stats[3], stats[5], stats[6], stats[7], stats[8])] == orc.stats()
+    assert (subdirs[0] / "compiled.csv").read_bytes().count(b"\r\n") == len(rows)
+
+
+def test_cli_directory_of_samples(tmp_path):
+    guides = synth.make_library(60, 20, 44)
+    (tmp_path / "in").mkdir()
+    csvp = tmp_path / "lib.csv"
+    csvp.write_text("".join(f"{100 - i},{g}\n" for i, g in enumerate(guides)))       # numeric names: int sort (:791)
+    exp = {}
+    for k, n in (("s1", 1500), ("s2", 700)):
+        fq = synth.make_fastq(synth.Spec(seed=30 + n, n_reads=n, read_len=50), guides)
+        (tmp_path / "in" / f"{k}.fastq").write_bytes(fq)
+        orc = O.Oracle(features=[(str(100 - i), g) for i, g in enumerate(guides)], miss=0)
+        orc.count_fastq(fq)
+        exp[k] = dict(zip(orc.names, orc.counts()))
+    fast2q.main(["-c", "--s", str(tmp_path / "in"), "--g", str(csvp), "--o", str(tmp_path), "--m", "0", "--pb", "--fn", "res"])
+    out = [d for d in tmp_path.iterdir() if d.is_dir() and d.name.startswith("2FAST2Q_output_")][0]
+    rows = list(csv.reader(open(out / "res.csv", newline="")))
+    assert rows[0] == ["#Feature", "s1", "s2"]
+    assert [r[0] for r in rows[1:]] == [str(v) for v in sorted(100 - i for i in range(60))]
+    for r in rows[1:]:
+        assert int(r[1]) == exp["s1"][r[0]] and int(r[2]) == exp["s2"][r[0]]
