@@ -26,6 +26,21 @@
 
 namespace f2q {
 
+// Pointers that arrive inside by-value structs or from memory are "generic" to the compiler, which
+// then emits flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) per access (flat ops complete out of order),
+// i.e. one memory round trip at a time.  gp()/gpw() re-type them as global (address space 1) so the
+// loads become global_load_* and stay in flight together.  On the host they are the identity.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define F2Q_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ const T F2Q_GLOBAL *gp(const T *p) { return (const T F2Q_GLOBAL *)p; }
+template <class T> __device__ __forceinline__ T F2Q_GLOBAL *gpw(T *p) { return (T F2Q_GLOBAL *)p; }
+#else
+#define F2Q_GLOBAL
+template <class T> F2Q_HD const T *gp(const T *p) { return p; }
+template <class T> F2Q_HD T *gpw(T *p) { return p; }
+#endif
+typedef const uint8_t F2Q_GLOBAL *gbytes;      // read-only bytes in device global memory
+
 static const uint64_t KEY_EMPTY = ~0ull;
 
 // ---------------------------------------------------------------------------------------------
@@ -47,8 +62,21 @@ struct RunDev {
 struct PieceDesc { uint32_t off, bits, shift, pad; uint64_t mask; };   // table = 1<<bits slots at tab[off]
 struct LenGroup { uint32_t n, n_pieces; PieceDesc exact; PieceDesc piece[F2Q_MAX_PIECES]; };
 
+// "packed" tables for the one feature length a fixed-offset run looks up (v2 fast kernel): a slot is
+// (2-bit key << ib) | feature index, so one 8-byte load resolves a probe; hashing is 32-bit.
+struct PackedPiece { uint32_t off, bits, shift, pad; uint64_t mask; };
+struct PackedGroup {
+    uint32_t len;                      // feature length these tables index (0: not built)
+    uint32_t ib;                       // index bits
+    uint32_t n_pieces, pad;
+    PackedPiece exact;
+    PackedPiece piece[F2Q_MAX_PIECES];
+};
+
 struct LibDev {
     uint32_t n_features, n_irregular;
+    const uint64_t *ptab;              // packed slots (KEY_EMPTY = free)
+    PackedGroup pk;
     const uint64_t *tab_keys;          // open-addressing slots: 2-bit feature key or KEY_EMPTY
     const uint32_t *tab_idx;           // feature index of the slot
     const uint8_t *feat_bytes;         // all features, raw (upper-case) bytes
@@ -63,6 +91,8 @@ struct LibDev {
 struct Accum {
     unsigned long long *counts;        // [n_features]
     unsigned long long *stats;         // [5]
+    uint32_t *slab;                    // [gridDim.x][n_features] per-workgroup histograms (or nullptr)
+    unsigned long long *stat_slab;     // [gridDim.x][8] per-workgroup stats (or nullptr)
 };
 
 struct EcDev {
@@ -81,7 +111,7 @@ struct EcDev {
 F2Q_HD void acc_add(unsigned long long *p, unsigned long long v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicAdd(p, v);
+    __hip_atomic_fetch_add(gpw(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     *p += v;
 #endif
@@ -90,6 +120,15 @@ F2Q_HD void acc_add(unsigned long long *p, unsigned long long v)
 F2Q_HD uint32_t hash_slot(uint64_t k, uint32_t bits)
 {
     return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64u - bits));
+}
+
+F2Q_HD uint32_t hash32(uint64_t k, uint32_t bits)
+{
+    uint32_t x = (uint32_t)k ^ ((uint32_t)(k >> 32) * 0x9E3779B1u);
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 15;
+    x *= 0xC2B2AE35u;
+    return x >> (32u - bits);
 }
 
 F2Q_HD uint8_t up8(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
@@ -144,9 +183,10 @@ F2Q_HD int lib_exact(const LibDev &lib, uint64_t key, int L)
     if (g.n == 0) return -1;
     const uint32_t m = (1u << g.exact.bits) - 1u;
     uint32_t s = hash_slot(key, g.exact.bits);
+    const auto tab_keys = gp(lib.tab_keys);
     for (;;) {
-        uint64_t k = lib.tab_keys[g.exact.off + s];
-        if (k == key) return (int)lib.tab_idx[g.exact.off + s];
+        uint64_t k = tab_keys[g.exact.off + s];
+        if (k == key) return (int)gp(lib.tab_idx)[g.exact.off + s];
         if (k == KEY_EMPTY) return -1;
         s = (s + 1) & m;
     }
@@ -162,6 +202,8 @@ F2Q_HD void lib_near(const LibDev &lib, uint64_t key, int L, uint64_t forced, Mi
     const LenGroup &g = lib.grp[L];
     if (g.n == 0) return;
     const int nforced = popc64(forced);
+    const auto tab_keys = gp(lib.tab_keys);
+    const auto tab_idx = gp(lib.tab_idx);
     for (uint32_t p = 0; p < g.n_pieces; p++) {
         const PieceDesc pd = g.piece[p];
         if ((forced >> pd.shift) & pd.mask & 0x5555555555555555ull) continue;   // piece can never agree
@@ -169,7 +211,7 @@ F2Q_HD void lib_near(const LibDev &lib, uint64_t key, int L, uint64_t forced, Mi
         const uint32_t m = (1u << pd.bits) - 1u;
         uint32_t s = hash_slot(pv, pd.bits);
         for (;;) {
-            uint64_t k = lib.tab_keys[pd.off + s];
+            uint64_t k = tab_keys[pd.off + s];
             if (k == KEY_EMPTY) break;
             uint64_t x = k ^ key;
             if (((x >> pd.shift) & pd.mask) == 0) {
@@ -181,7 +223,7 @@ F2Q_HD void lib_near(const LibDev &lib, uint64_t key, int L, uint64_t forced, Mi
                 }
                 if (!dup) {
                     uint64_t xm = x & ~(forced | (forced << 1));
-                    t.offer(ham2(xm) + nforced, lib.tab_idx[pd.off + s]);
+                    t.offer(ham2(xm) + nforced, tab_idx[pd.off + s]);
                 }
             }
             s = (s + 1) & m;
@@ -192,8 +234,9 @@ F2Q_HD void lib_near(const LibDev &lib, uint64_t key, int L, uint64_t forced, Mi
 // ---------------------------------------------------------------------------------------------
 // general path: keys as byte strings (any symbols, any length, ':'-joined multi-window keys)
 // ---------------------------------------------------------------------------------------------
-struct KeyView {
-    const uint8_t *seq;                 // the read's sequence line (raw case)
+template <class P>
+struct KeyViewT {
+    P seq;                              // the read's sequence line (raw case)
     int nseg; int a[F2Q_DEV_MAX_ITER], b[F2Q_DEV_MAX_ITER];
     int len;                            // total key length incl. ':' separators
     F2Q_HD uint8_t at(int k) const
@@ -207,9 +250,12 @@ struct KeyView {
         return 0;
     }
 };
+typedef KeyViewT<const uint8_t *> KeyView;      // key bytes in any address space (e.g. a register-built window)
+typedef KeyViewT<gbytes> KeyViewG;              // key bytes inside a raw record in global memory
 
 // distance between the key and feature f (same length), giving up once it exceeds `limit`
-F2Q_HD int key_dist(const KeyView &kv, const uint8_t *fb, int limit)
+template <class KV>
+F2Q_HD int key_dist(const KV &kv, gbytes fb, int limit)
 {
     int d = 0, k = 0;
     for (int s = 0; s < kv.nseg; s++) {
@@ -222,20 +268,24 @@ F2Q_HD int key_dist(const KeyView &kv, const uint8_t *fb, int limit)
 }
 
 // brute force over a list of features (ids == nullptr: all features)
-F2Q_HD void lib_scan(const LibDev &lib, const KeyView &kv, const uint32_t *ids, uint32_t n, MinTrack &t)
+template <class KV>
+F2Q_HD void lib_scan(const LibDev &lib, const KV &kv, const uint32_t *ids_, uint32_t n, MinTrack &t)
 {
+    const auto ids = gp(ids_);
+    const auto feat_off = gp(lib.feat_off);
     for (uint32_t e = 0; e < n; e++) {
-        uint32_t f = ids ? ids[e] : e;
-        uint32_t o = lib.feat_off[f];
-        if ((int)(lib.feat_off[f + 1] - o) != kv.len) continue;          // only same-length features (:683)
-        int d = key_dist(kv, lib.feat_bytes + o, t.best);
+        uint32_t f = ids_ ? ids[e] : e;
+        uint32_t o = feat_off[f];
+        if ((int)(feat_off[f + 1] - o) != kv.len) continue;              // only same-length features (:683)
+        int d = key_dist(kv, gp(lib.feat_bytes) + o, t.best);
         if (d <= t.best) t.offer(d, f);
     }
 }
 
 // Counter-mode decision for one extracted key: returns 1 perfect, 2 imperfect, 3 non-aligned,
 // and the feature index in `idx`.
-F2Q_HD int match_key(const RunDev &run, const LibDev &lib, const KeyView &kv, uint32_t &idx)
+template <class KV>
+F2Q_HD int match_key(const RunDev &run, const LibDev &lib, const KV &kv, uint32_t &idx)
 {
     // is the key a plain ACGT string short enough for the 2-bit index?
     bool regular = (kv.nseg == 1 && kv.len >= 1 && kv.len <= F2Q_REG_MAXLEN);
@@ -267,7 +317,8 @@ F2Q_HD int match_key(const RunDev &run, const LibDev &lib, const KeyView &kv, ui
 }
 
 // Phred test of quality bytes [a,b) against threshold thr
-F2Q_HD bool qual_range_fails(const uint8_t *q, int a, int b, int thr)
+template <class P>
+F2Q_HD bool qual_range_fails(P q, int a, int b, int thr)
 {
     if (thr < 33) return false;
     for (int i = a; i < b; i++) if (q_fails(q[i], thr)) return true;
@@ -275,7 +326,8 @@ F2Q_HD bool qual_range_fails(const uint8_t *q, int a, int b, int thr)
 }
 
 // border_finder (:628-658) on raw bytes: first p in [from, r-s] within k mismatches, else -1
-F2Q_HD int border_find(const uint8_t *anchor, int s, const uint8_t *read, int r, int k, int from)
+template <class P>
+F2Q_HD int border_find(gbytes anchor, int s, P read, int r, int k, int from)
 {
     if (from < 0) from = 0;
     for (int p = from; p + s <= r && p < r; p++) {
@@ -287,14 +339,14 @@ F2Q_HD int border_find(const uint8_t *anchor, int s, const uint8_t *read, int r,
 }
 
 // sequence_tinder (:215-285): true + (start,end) or false
-F2Q_HD bool tinder(const RunDev &run, const uint8_t *seq, int r, const uint8_t *qual, int qn, int i,
-                   int &start, int &end)
+template <class P>
+F2Q_HD bool tinder(const RunDev &run, P seq, int r, P qual, int qn, int i, int &start, int &end)
 {
     int a, b;
     if (run.has_up && run.has_down) {
-        int st = border_find(run.up[i], run.up_len[i], seq, r, run.msu, 0);
+        int st = border_find(gp(&run.up[i][0]), run.up_len[i], seq, r, run.msu, 0);
         if (st < 0) return false;
-        int en = border_find(run.down[i], run.down_len[i], seq, r, run.msd, st + run.up_len[i]);
+        int en = border_find(gp(&run.down[i][0]), run.down_len[i], seq, r, run.msd, st + run.up_len[i]);
         if (en < 0) return false;
         py_slice(qn, st, st + run.up_len[i], a, b);
         if (qual_range_fails(qual, a, b, run.thr_up)) return false;
@@ -303,14 +355,14 @@ F2Q_HD bool tinder(const RunDev &run, const uint8_t *seq, int r, const uint8_t *
         start = st + run.up_len[i]; end = en;
         return true;
     } else if (run.has_up) {
-        int st = border_find(run.up[i], run.up_len[i], seq, r, run.msu, 0);
+        int st = border_find(gp(&run.up[i][0]), run.up_len[i], seq, r, run.msu, 0);
         if (st < 0) return false;
         py_slice(qn, st, st + run.up_len[i], a, b);
         if (qual_range_fails(qual, a, b, run.thr_up)) return false;
         start = st + run.up_len[i]; end = start + run.length;
         return true;
     } else if (run.has_down) {
-        int en = border_find(run.down[i], run.down_len[i], seq, r, run.msd, 0);
+        int en = border_find(gp(&run.down[i][0]), run.down_len[i], seq, r, run.msd, 0);
         if (en < 0) return false;
         py_slice(qn, en, en + run.down_len[i], a, b);
         if (qual_range_fails(qual, a, b, run.thr_down)) return false;
@@ -323,7 +375,8 @@ F2Q_HD bool tinder(const RunDev &run, const uint8_t *seq, int r, const uint8_t *
 // ---------------------------------------------------------------------------------------------
 // EC byte-string table (device side of the de-novo dict, :382-387)
 // ---------------------------------------------------------------------------------------------
-F2Q_HD uint64_t key_hash(const KeyView &kv)
+template <class KV>
+F2Q_HD uint64_t key_hash(const KV &kv)
 {
     uint64_t h = 1469598103934665603ull ^ (uint64_t)kv.len;
     for (int k = 0; k < kv.len; k++) { h ^= kv.at(k); h *= 1099511628211ull; }
@@ -332,10 +385,10 @@ F2Q_HD uint64_t key_hash(const KeyView &kv)
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define F2Q_LD64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define F2Q_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define F2Q_ST64(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define F2Q_ST32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F2Q_LD64(p) __hip_atomic_load(gpw(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F2Q_LD32(p) __hip_atomic_load(gpw(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F2Q_ST64(p, v) __hip_atomic_store(gpw(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define F2Q_ST32(p, v) __hip_atomic_store(gpw(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define F2Q_LD64(p) (*(p))
 #define F2Q_LD32(p) (*(p))
@@ -346,7 +399,8 @@ F2Q_HD uint64_t key_hash(const KeyView &kv)
 F2Q_HD unsigned long long ec_cas(unsigned long long *p, unsigned long long cmp, unsigned long long val)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return atomicCAS(p, cmp, val);
+    __hip_atomic_compare_exchange_strong(gpw(p), &cmp, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return cmp;
 #else
     unsigned long long old = *p; if (old == cmp) *p = val; return old;
 #endif
@@ -354,7 +408,7 @@ F2Q_HD unsigned long long ec_cas(unsigned long long *p, unsigned long long cmp, 
 F2Q_HD unsigned long long ec_fetch_add(unsigned long long *p, unsigned long long v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(p, v);
+    return __hip_atomic_fetch_add(gpw(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     unsigned long long old = *p; *p += v; return old;
 #endif
@@ -362,13 +416,14 @@ F2Q_HD unsigned long long ec_fetch_add(unsigned long long *p, unsigned long long
 F2Q_HD void ec_min(unsigned long long *p, unsigned long long v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicMin(p, v);
+    __hip_atomic_fetch_min(gpw(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     if (v < *p) *p = v;
 #endif
 }
 
-F2Q_HD uint32_t key_word(const KeyView &kv, int w)
+template <class KV>
+F2Q_HD uint32_t key_word(const KV &kv, int w)
 {
     uint32_t v = 0;
     for (int j = 0; j < 4; j++) { int k = 4 * w + j; if (k < kv.len) v |= (uint32_t)kv.at(k) << (8 * j); }
@@ -379,7 +434,8 @@ F2Q_HD uint32_t key_word(const KeyView &kv, int w)
 // the table is coherent across XCDs inside one launch.  A slot is claimed with one CAS (locked),
 // filled, then published; lanes that meet a locked slot of the same fingerprint re-poll it.  The
 // claimer never waits on anybody, so the loop cannot deadlock inside a wave; polls are bounded.
-F2Q_HD void ec_insert(const EcDev &ec, const KeyView &kv, unsigned long long read_index)
+template <class KV>
+F2Q_HD void ec_insert(const EcDev &ec, const KV &kv, unsigned long long read_index)
 {
     const uint64_t h = key_hash(kv);
     const unsigned long long fp = (h >> 32) & 0xFFFFFFFFull;
@@ -435,11 +491,12 @@ F2Q_HD void ec_insert(const EcDev &ec, const KeyView &kv, unsigned long long rea
 // ---------------------------------------------------------------------------------------------
 // general path: one read given as raw bytes.  st[] = the 5 reference counters (thread-local).
 // ---------------------------------------------------------------------------------------------
+template <class P>
 F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, const Accum &acc,
-                         const uint8_t *seq, int r, const uint8_t *qual, int qn,
+                         P seq, int r, P qual, int qn,
                          unsigned long long read_index, unsigned long long st[5])
 {
-    KeyView kv; kv.seq = seq; kv.nseg = 0; kv.len = 0;
+    KeyViewT<P> kv; kv.seq = seq; kv.nseg = 0; kv.len = 0;
     bool all_failed = true;
     for (int i = 0; i < run.n_iter; i++) {
         int start, end;
@@ -498,7 +555,7 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
 {
     int rlen = (int)pb.rmax;
     if (pb.len) {
-        uint32_t l = pb.len[(uint64_t)tile * F2Q_TILE + lane];
+        uint32_t l = gp(pb.len)[(uint64_t)tile * F2Q_TILE + lane];
         if (l == F2Q_LEN_SKIP) return 0;
         rlen = (int)l;
     }
@@ -510,7 +567,7 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
     if (run.thr >= 33 && L > 0) {
         const uint32_t add_lo = 0x5F5F5F5Fu;                                   // +95
         const uint32_t add_hi = (uint32_t)(127 - run.thr) * 0x01010101u;
-        const uint32_t *qp = pb.qual + ((uint64_t)tile * pb.wq) * F2Q_TILE + lane;
+        const auto qp = gp(pb.qual) + ((uint64_t)tile * pb.wq) * F2Q_TILE + lane;
         uint32_t bad = 0;
         const int w0 = a >> 2, w1 = (b - 1) >> 2;
         for (int w = w0; w <= w1; w++) {
@@ -524,7 +581,7 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
     // ---- 2-bit key of bases [a,b) ----
     uint64_t key = 0;
     if (L > 0) {
-        const uint32_t *bp = pb.bases + ((uint64_t)tile * pb.wb) * F2Q_TILE + lane;
+        const auto bp = gp(pb.bases) + ((uint64_t)tile * pb.wb) * F2Q_TILE + lane;
         const int w0 = a >> 4, w1 = (b - 1) >> 4;              // at most 3 words for L <= 31
         uint64_t lo = bp[(uint64_t)w0 * F2Q_TILE];
         uint64_t mid = (w1 > w0) ? bp[(uint64_t)(w0 + 1) * F2Q_TILE] : 0u;
@@ -556,6 +613,123 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
     }
     if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? 1 : 2; }
     return 3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast path v2: one wave per 256-read tile, lane l owns reads 4l..4l+3 so that every tile row is
+// fetched with one 16-byte load per lane; probes go to the packed tables.
+// ---------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+F2Q_HD uint32_t u4get(const U4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+#define F2Q_MAXQROWS 9     // a <= 31-base window touches at most 9 quality words
+#define F2Q_MAXBROWS 3     // ... and at most 3 base words
+
+// wave-uniform geometry of the window in tile rows
+struct FixedGeom {
+    int st, L;                 // window start / length (full, unclipped)
+    int qw0, nq;               // first quality row, number of rows
+    int bw0, nb;               // first base row, number of rows
+    uint32_t qm_first, qm_last;   // 0x80-per-byte masks of the bytes tested in the first / last row
+    uint32_t add_lo, add_hi;   // SWAR constants of the Phred rule (thr >= 33), add_hi == 0: rule off
+    int sh;                    // bit offset of the window inside the first base row
+    uint64_t kmask;            // (1 << 2L) - 1
+};
+
+F2Q_HD FixedGeom fixed_geom(const RunDev &run)
+{
+    FixedGeom g;
+    g.st = run.start[0]; g.L = run.length;
+    const int a = g.st, b = g.st + g.L;
+    g.qw0 = a >> 2; g.nq = g.L > 0 ? ((b - 1) >> 2) - g.qw0 + 1 : 0;
+    g.bw0 = a >> 4; g.nb = g.L > 0 ? ((b - 1) >> 4) - g.bw0 + 1 : 0;
+    g.qm_first = 0x80808080u & (0xFFFFFFFFu << (8 * (a & 3)));
+    g.qm_last = g.L > 0 ? (0x80808080u & (0xFFFFFFFFu >> (8 * (3 - ((b - 1) & 3))))) : 0u;
+    if (g.nq == 1) { g.qm_first &= g.qm_last; g.qm_last = g.qm_first; }
+    g.add_lo = 0x5F5F5F5Fu;
+    g.add_hi = run.thr >= 33 ? (uint32_t)(127 - run.thr) * 0x01010101u : 0u;
+    g.sh = 2 * (a & 15);
+    g.kmask = g.L >= 32 ? ~0ull : ((1ull << (2 * g.L)) - 1ull);
+    return g;
+}
+
+// result codes of one read in the v2 kernel
+enum { R_SKIP = 0, R_PERFECT = 1, R_IMPERFECT = 2, R_NONALIGNED = 3, R_QFAIL = 4, R_SLOW = 5, R_NEAR = 6 };
+
+// Phred test of one quality row for the 4 reads of a lane (bad[j] != 0: read j fails)
+F2Q_HD void fixed4_qrow(const FixedGeom &g, int r, const U4 &q, uint32_t bad[4])
+{
+    const uint32_t m = (r == 0) ? g.qm_first : (r == g.nq - 1) ? g.qm_last : 0x80808080u;
+    bad[0] |= qfail4(q.x, g.add_lo, g.add_hi, m);
+    bad[1] |= qfail4(q.y, g.add_lo, g.add_hi, m);
+    bad[2] |= qfail4(q.z, g.add_lo, g.add_hi, m);
+    bad[3] |= qfail4(q.w, g.add_lo, g.add_hi, m);
+}
+
+// 2-bit key of read j of a lane from the base rows the lane loaded
+template <int BR>
+F2Q_HD uint64_t fixed4_key(const FixedGeom &g, const U4 (&b)[BR], int j)
+{
+    uint64_t lo = u4get(b[0], j);
+    uint64_t mid = (BR > 1 && g.nb > 1) ? u4get(b[BR > 1 ? 1 : 0], j) : 0u;
+    uint64_t hi = (BR > 2 && g.nb > 2) ? u4get(b[BR > 2 ? 2 : 0], j) : 0u;
+    uint64_t k = (lo | (mid << 32)) >> g.sh;
+    if (g.sh) k |= hi << (64 - g.sh);
+    return k & g.kmask;
+}
+
+// exact probe of the packed table: feature index or -1.  Two slots are fetched per round.
+F2Q_HD int packed_exact(const LibDev &lib, uint64_t key)
+{
+    const PackedPiece &e = lib.pk.exact;
+    const uint32_t m = (1u << e.bits) - 1u, ib = lib.pk.ib;
+    uint32_t s = hash32(key, e.bits);
+    const auto ptab = gp(lib.ptab);
+    for (;;) {
+        uint64_t v0 = ptab[e.off + s], v1 = ptab[e.off + ((s + 1) & m)];
+        if (v0 != KEY_EMPTY && (v0 >> ib) == key) return (int)(v0 & ((1ull << ib) - 1ull));
+        if (v0 == KEY_EMPTY) return -1;
+        if (v1 != KEY_EMPTY && (v1 >> ib) == key) return (int)(v1 & ((1ull << ib) - 1ull));
+        if (v1 == KEY_EMPTY) return -1;
+        s = (s + 2) & m;
+    }
+}
+
+// pigeonhole search on the packed piece tables (regular query, no forced positions)
+F2Q_HD void packed_near(const LibDev &lib, uint64_t key, MinTrack &t)
+{
+    const uint32_t ib = lib.pk.ib;
+    const uint64_t imask = (1ull << ib) - 1ull;
+    const auto ptab = gp(lib.ptab);
+    for (uint32_t p = 0; p < lib.pk.n_pieces; p++) {
+        const PackedPiece pd = lib.pk.piece[p];
+        const uint64_t pv = (key >> pd.shift) & pd.mask;
+        const uint32_t m = (1u << pd.bits) - 1u;
+        uint32_t s = hash32(pv, pd.bits);
+        for (;;) {
+            uint64_t v = ptab[pd.off + s];
+            if (v == KEY_EMPTY) break;
+            uint64_t x = (v >> ib) ^ key;
+            if (((x >> pd.shift) & pd.mask) == 0) {
+                bool dup = false;
+                for (uint32_t q = 0; q < p; q++) {
+                    const PackedPiece qd = lib.pk.piece[q];
+                    if (((x >> qd.shift) & qd.mask) == 0) { dup = true; break; }
+                }
+                if (!dup) t.offer(ham2(x), (uint32_t)(v & imask));
+            }
+            s = (s + 1) & m;
+        }
+    }
+}
+
+// decision for a key whose exact probe missed (the work the v2 kernel queues and compacts)
+F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key, uint32_t &idx)
+{
+    MinTrack t; t.init(run.miss);
+    packed_near(lib, key, t);
+    if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? R_PERFECT : R_IMPERFECT; }
+    return R_NONALIGNED;
 }
 
 } // namespace f2q

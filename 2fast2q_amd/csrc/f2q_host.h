@@ -22,6 +22,8 @@ struct HostIndex {
     std::vector<uint32_t> feat_off;
     std::vector<uint32_t> irr_ids;
     std::vector<uint64_t> key2;          // 2-bit key per feature (0 for irregular ones)
+    std::vector<uint64_t> ptab;          // packed slots of the run's feature length (v2 fast kernel)
+    PackedGroup pk;
     LenGroup grp[F2Q_REG_MAXLEN + 1];
     uint32_t n_features = 0, n_irregular = 0;
 };
@@ -53,7 +55,46 @@ inline void table_insert(std::vector<uint64_t> &keys, std::vector<uint32_t> &idx
     keys[pd.off + s] = full_key; idx[pd.off + s] = id;
 }
 
-inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss)
+inline void packed_insert(std::vector<uint64_t> &tab, const PackedPiece &pd, uint64_t hashed, uint64_t slot)
+{
+    uint32_t m = (1u << pd.bits) - 1u, s = hash32(hashed, pd.bits);
+    while (tab[pd.off + s] != KEY_EMPTY) s = (s + 1) & m;
+    tab[pd.off + s] = slot;
+}
+
+// packed tables for features of length `len` (the window length of a fixed-offset run): built when
+// key bits + index bits fit one u64 and the pigeonhole pieces are regular
+inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int len, int miss)
+{
+    memset(&ix.pk, 0, sizeof ix.pk);
+    ix.ptab.assign(1, KEY_EMPTY);
+    if (len < 1 || len > F2Q_REG_MAXLEN || ids.empty()) return;
+    uint32_t ib = 1;
+    while ((1ull << ib) < (uint64_t)ix.n_features + 1) ib++;
+    if (2 * len + (int)ib > 64) return;
+    const int P = miss > 0 ? miss + 1 : 0;
+    if (P > len || P > F2Q_MAX_PIECES) return;
+    const uint32_t bits = table_bits((uint32_t)ids.size()) + 1;          // load factor <= 0.25
+    if (bits > 30) return;
+    PackedGroup &g = ix.pk;
+    g.len = (uint32_t)len; g.ib = ib; g.n_pieces = (uint32_t)P;
+    uint32_t off = 0;
+    g.exact.off = off; g.exact.bits = bits; g.exact.shift = 0; g.exact.mask = ~0ull; off += 1u << bits;
+    for (int p = 0; p < P; p++) {
+        int b0 = (int)((long)p * len / P), b1 = (int)((long)(p + 1) * len / P);
+        g.piece[p].off = off; g.piece[p].bits = bits; off += 1u << bits;
+        g.piece[p].shift = (uint32_t)(2 * b0);
+        g.piece[p].mask = (b1 - b0 >= 32) ? ~0ull : ((1ull << (2 * (b1 - b0))) - 1ull);
+    }
+    ix.ptab.assign(off, KEY_EMPTY);
+    for (uint32_t f : ids) {
+        const uint64_t k = ix.key2[f], slot = (k << ib) | f;
+        packed_insert(ix.ptab, g.exact, k, slot);
+        for (int p = 0; p < P; p++) packed_insert(ix.ptab, g.piece[p], (k >> g.piece[p].shift) & g.piece[p].mask, slot);
+    }
+}
+
+inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss, int packed_len = 0)
 {
     ix = HostIndex();
     ix.n_features = n;
@@ -106,6 +147,8 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
                 table_insert(ix.tab_keys, ix.tab_idx, g.piece[p], (k >> g.piece[p].shift) & g.piece[p].mask, k, f);
         }
     }
+    build_packed(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(),
+                 packed_len, miss);
     ix.n_irregular = (uint32_t)ix.irr_ids.size();
     if (ix.irr_ids.empty()) ix.irr_ids.push_back(0);     // keep the device array non-empty
 }

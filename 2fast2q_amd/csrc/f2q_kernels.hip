@@ -37,6 +37,27 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
+// Workgroup-level sum of the 5 reference counters: same-address global atomics serialise in L2
+// (20k of them cost ~0.2 ms per launch), so a workgroup issues at most one per counter -- or none
+// when it can leave its sums in a slab row for k_reduce_slabs.
+__device__ __forceinline__ void flush_stats(const Accum &acc, unsigned long long st[5], unsigned long long *lds8,
+                                            unsigned long long *slab_row)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < 8) lds8[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = 0; k < 5; k++) {
+        unsigned long long v = wave_sum(st[k]);
+        if (lane == 0 && v) atomicAdd(&lds8[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        unsigned long long v = lds8[threadIdx.x];
+        if (slab_row) gpw(slab_row)[threadIdx.x] = v;
+        else if (v) acc_add(&acc.stats[threadIdx.x], v);
+    }
+}
+
 // Fast path, fixed offset.  Persistent workgroups stride over the tiles.  USE_LDS: per-workgroup
 // u32 histogram in LDS, flushed once with 64-bit global atomics.
 template <bool USE_LDS>
@@ -58,24 +79,236 @@ __global__ __launch_bounds__(F2Q_TILE) void k_count_fixed(const RunDev *__restri
         int res = fixed_lane(run, lib, pb, tile, threadIdx.x, idx);
         if (res == 1 || res == 2) {
             if (USE_LDS) atomicAdd(&hist[idx], 1u);
-            else atomicAdd(&acc.counts[idx], 1ull);
+            else acc_add(&acc.counts[idx], 1ull);
         }
         st0 += (res != 0); st1 += (res == 1); st2 += (res == 2); st3 += (res == 3); st4 += (res == 4);
     }
-    st0 = wave_sum(st0); st1 = wave_sum(st1); st2 = wave_sum(st2); st3 = wave_sum(st3); st4 = wave_sum(st4);
-    if ((threadIdx.x & 63) == 0) {
-        if (st0) atomicAdd(&acc.stats[0], st0);
-        if (st1) atomicAdd(&acc.stats[1], st1);
-        if (st2) atomicAdd(&acc.stats[2], st2);
-        if (st3) atomicAdd(&acc.stats[3], st3);
-        if (st4) atomicAdd(&acc.stats[4], st4);
-    }
+    __shared__ unsigned long long st_lds[8];
+    unsigned long long stv[5] = {st0, st1, st2, st3, st4};
+    flush_stats(acc, stv, st_lds, nullptr);
     if (USE_LDS) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < nf; i += F2Q_TILE) {
             uint32_t c = hist[i];
-            if (c) atomicAdd(&acc.counts[i], (unsigned long long)c);
+            if (c) acc_add(&acc.counts[i], (unsigned long long)c);
         }
+    }
+}
+
+// ---- fast path v2 -----------------------------------------------------------------------------------
+// One wave per 256-read tile, lane l owns reads 4l..4l+3: every tile row is one 16-byte load per lane
+// (1 KiB per wave instruction).  Exact probes hit the packed table (key|index in one u64, two slots in
+// flight per round, four reads in flight per lane).  Reads whose exact probe misses are not searched in
+// place -- that would run the pigeonhole chains with ~15 % of the lanes active -- but pushed into an LDS
+// ring; once a workgroup's ring holds a full workgroup of keys they are searched one per lane.
+#define F2Q_V2_THREADS 512
+#define F2Q_V2_WAVES (F2Q_V2_THREADS / 64)
+#define F2Q_V2_QCAP 4096u
+
+template <bool NT>
+__device__ __forceinline__ U4 ld_u4(const uint32_t F2Q_GLOBAL *p)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 F2Q_GLOBAL *q = (const v4 F2Q_GLOBAL *)p;
+    v4 v = NT ? __builtin_nontemporal_load(q) : *q;      // NT: stream once, keep L2 for the tables
+    return U4{v.x, v.y, v.z, v.w};
+}
+
+__device__ __noinline__ int slow_read(const RunDev *run, const LibDev *lib, const PackedBlock *pb, uint32_t tile,
+                                      uint32_t slot, uint32_t *idx)
+{
+    return fixed_lane(*run, *lib, *pb, tile, slot, *idx);
+}
+__device__ __noinline__ int near_read(const RunDev *run, const LibDev *lib, uint64_t key, uint32_t *idx)
+{
+    return packed_near_decide(*run, *lib, key, *idx);
+}
+
+// NQ / NB: number of quality / base rows under the window when known at compile time (the common
+// geometries get their own instantiation so that all row loads sit in one basic block and issue
+// back to back); 0 = run-time geometry, rows beyond the window are clamped re-loads of the last one.
+template <bool USE_LDS, int NQ, int NB>
+__global__ __launch_bounds__(F2Q_V2_THREADS) void k_count_fixed4(const RunDev *__restrict__ runp,
+                                                                  const LibDev *__restrict__ libp, PackedBlock pb,
+                                                                  Accum acc)
+{
+    extern __shared__ unsigned long long smem64[];
+    unsigned long long *queue = smem64;                                   // F2Q_V2_QCAP keys
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_QCAP);  // n_features counters (USE_LDS)
+    __shared__ uint32_t q_head, q_tail;
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (USE_LDS) for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) hist[i] = 0;
+    if (tid == 0) { q_head = 0; q_tail = 0; }
+    __syncthreads();
+    const FixedGeom g = fixed_geom(run);
+    const int need = g.st + g.L;
+    const bool do_near = run.miss > 0;
+    const PackedPiece ex = lib.pk.exact;
+    const uint32_t ib = lib.pk.ib, exm = (1u << ex.bits) - 1u;
+    const uint64_t imask = (1ull << ib) - 1ull;
+    const auto ptab = gp(lib.ptab);
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+
+    auto count_hit = [&](uint32_t idx) {
+        if (USE_LDS) atomicAdd(&hist[idx], 1u);
+        else acc_add(&acc.counts[idx], 1ull);
+    };
+
+    for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
+        const uint32_t tile = base + wave;
+        int res[4] = {R_SKIP, R_SKIP, R_SKIP, R_SKIP};
+        uint64_t key[4] = {0, 0, 0, 0};
+        if (tile < pb.n_tiles) {
+            constexpr int QR = NQ ? NQ : F2Q_MAXQROWS, BR = NB ? NB : F2Q_MAXBROWS;
+            constexpr bool NT = true;                    // tile rows are streamed once: keep L2 for the tables
+            U4 brow[BR], qrow[QR];
+            const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane;
+            const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane;
+            // every load of the tile is issued before anything is consumed
+#pragma unroll
+            for (int r = 0; r < BR; r++) {
+                uint32_t row = (uint32_t)g.bw0 + (uint32_t)(NB ? r : (r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0)));
+                row = row < pb.wb ? row : pb.wb - 1u;       // reads shorter than the window: stay inside the tile
+                brow[r] = ld_u4<NT>(bp + (uint64_t)row * F2Q_TILE);
+            }
+#pragma unroll
+            for (int r = 0; r < QR; r++) {
+                uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0)));
+                row = row < pb.wq ? row : pb.wq - 1u;
+                qrow[r] = ld_u4<NT>(qp + (uint64_t)row * F2Q_TILE);
+            }
+            uint32_t len01 = 0, len23 = 0;
+            if (pb.len) {
+                typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+                v2 lv = *(const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)tile * F2Q_TILE + 4u * lane);
+                len01 = lv.x; len23 = lv.y;
+            }
+            uint32_t bad[4] = {0, 0, 0, 0};
+            if (g.add_hi) {
+#pragma unroll
+                for (int r = 0; r < QR; r++)
+                    if (NQ || r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+                if (l == F2Q_LEN_SKIP) res[j] = R_SKIP;
+                else if ((int)l < need || g.L < 1) res[j] = R_SLOW;
+                else if (bad[j]) res[j] = R_QFAIL;
+                else { res[j] = R_NEAR; key[j] = fixed4_key(g, brow, j); }
+            }
+            // exact probes: up to 4 reads x 2 slots in flight per lane
+            uint32_t s[4]; bool pend[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pend[j] = (res[j] == R_NEAR); s[j] = hash32(key[j], ex.bits); }
+            while (pend[0] | pend[1] | pend[2] | pend[3]) {
+                uint64_t v0[4], v1[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (pend[j]) { v0[j] = ptab[ex.off + s[j]]; v1[j] = ptab[ex.off + ((s[j] + 1u) & exm)]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!pend[j]) continue;
+                    if (v0[j] == KEY_EMPTY) pend[j] = false;
+                    else if ((v0[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v0[j] & imask)); }
+                    else if (v1[j] == KEY_EMPTY) pend[j] = false;
+                    else if ((v1[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v1[j] & imask)); }
+                    else s[j] = (s[j] + 2u) & exm;
+                }
+            }
+            uint32_t npush = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (res[j] == R_SLOW) {                    // clipped window / odd geometry: the one-read routine
+                    uint32_t idx = 0;
+                    int r1 = slow_read(runp, libp, &pb, tile, 4u * lane + (uint32_t)j, &idx);
+                    if (r1 == 1 || r1 == 2) count_hit(idx);
+                    res[j] = r1;
+                } else if (res[j] == R_NEAR) {
+                    if (do_near) npush++; else res[j] = R_NONALIGNED;
+                }
+                st0 += (res[j] != R_SKIP); st1 += (res[j] == R_PERFECT); st2 += (res[j] == R_IMPERFECT);
+                st3 += (res[j] == R_NONALIGNED); st4 += (res[j] == R_QFAIL);
+            }
+            if (npush) {
+                uint32_t at = atomicAdd(&q_tail, npush);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (res[j] == R_NEAR) { queue[at % F2Q_V2_QCAP] = key[j]; at++; }
+            }
+        }
+        if (do_near) {
+            __syncthreads();
+            uint32_t head = q_head;
+            const uint32_t tail = q_tail;
+            while (tail - head >= F2Q_V2_THREADS) {
+                uint32_t idx = 0;
+                int r = near_read(runp, libp, queue[(head + tid) % F2Q_V2_QCAP], &idx);
+                if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
+                head += F2Q_V2_THREADS;
+            }
+            __syncthreads();
+            if (tid == 0) q_head = head;
+        }
+    }
+    if (do_near) {
+        __syncthreads();
+        const uint32_t head = q_head, tail = q_tail;
+        if (tid < tail - head) {
+            uint32_t idx = 0;
+            int r = near_read(runp, libp, queue[(head + tid) % F2Q_V2_QCAP], &idx);
+            if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
+        }
+    }
+    __shared__ unsigned long long st_lds[8];
+    unsigned long long stv[5] = {st0, st1, st2, st3, st4};
+    flush_stats(acc, stv, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
+    if (USE_LDS) {
+        // the workgroup's histogram leaves as one coalesced slab row; k_reduce_slabs sums the rows
+        __syncthreads();
+        auto row = gpw(acc.slab) + (uint64_t)blockIdx.x * nf;
+        for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) row[i] = hist[i];
+    }
+}
+
+// counts[f] += sum over workgroups of slab[w][f].  Block = 64 features x 4 row lanes; grid.y splits
+// the rows further so that every thread has ~16 independent loads in flight.
+#define F2Q_RED_SPLIT 8u
+__global__ __launch_bounds__(256) void k_reduce_slabs(const uint32_t *__restrict__ slab, uint32_t n_rows, uint32_t nf,
+                                                       unsigned long long *__restrict__ counts,
+                                                       const unsigned long long *__restrict__ stat_slab,
+                                                       unsigned long long *__restrict__ stats)
+{
+    __shared__ unsigned long long part[256];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && stat_slab) {          // the 5 reference counters: rows of 8
+        const uint32_t k = threadIdx.x & 7u, sub = threadIdx.x >> 3;   // 32 row lanes x 8 columns
+        unsigned long long sv = 0;
+        if (k < 5) for (uint32_t w = sub; w < n_rows; w += 32u) sv += stat_slab[(uint64_t)w * 8u + k];
+        part[threadIdx.x] = sv;
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            unsigned long long tot = 0;
+            for (uint32_t q = 0; q < 32u; q++) tot += part[q * 8u + threadIdx.x];
+            if (tot) atomicAdd(&stats[threadIdx.x], tot);
+        }
+        __syncthreads();
+    }
+    const uint32_t fx = threadIdx.x & 63u, ry = threadIdx.x >> 6;
+    const uint32_t f = blockIdx.x * 64u + fx;
+    unsigned long long sum = 0;
+    if (f < nf) {
+        const uint32_t step = F2Q_RED_SPLIT * 4u;
+#pragma unroll 8
+        for (uint32_t w = blockIdx.y * 4u + ry; w < n_rows; w += step) sum += slab[(uint64_t)w * nf + f];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (ry == 0 && f < nf) {
+        sum = part[fx] + part[64 + fx] + part[128 + fx] + part[192 + fx];
+        if (sum) atomicAdd(&counts[f], sum);
     }
 }
 
@@ -96,15 +329,13 @@ __global__ __launch_bounds__(256) void k_count_general(const RunDev *__restrict_
     unsigned long long st[5] = {0, 0, 0, 0, 0};
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rb.n;
          i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint8_t *seq = rb.raw + rb.off[i];
-        const int r = (int)rb.len[i], qn = (int)rb.qlen[i];
-        const unsigned long long gi = rb.first_index + (rb.index ? rb.index[i] : i);
+        gbytes seq = gp(rb.raw) + gp(rb.off)[i];
+        const int r = (int)gp(rb.len)[i], qn = (int)gp(rb.qlen)[i];
+        const unsigned long long gi = rb.first_index + (rb.index ? gp(rb.index)[i] : i);
         general_read(run, lib, ec, acc, seq, r, seq + r, qn, gi, st);
     }
-    for (int k = 0; k < 5; k++) {
-        unsigned long long v = wave_sum(st[k]);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc.stats[k], v);
-    }
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
 }
 
 // re-insert every entry of `old` into `nw` (table growth)
@@ -226,12 +457,18 @@ struct f2q_ctx {
     // accumulators: counts[n_features] then stats[5]
     unsigned long long *acc_d = nullptr;
     uint64_t acc_n = 0;
+    uint32_t *slab_d = nullptr;          // per-workgroup histogram rows of the v2 kernel
+    size_t slab_n = 0;
+    unsigned long long *stat_slab_d = nullptr;
+    size_t stat_slab_n = 0;
     // Extract+Count table
     EcDev ec{};
     std::vector<void *> ec_allocs;
     uint64_t ec_slots = 0;
     uint64_t reads_seen = 0;             // global read index of the next block's read 0
     int n_cu = 256;
+    bool force_generic = false;           // F2Q_GENERIC=1: run-time window geometry even where a specialisation exists
+    bool force_v1 = false;                // F2Q_FORCE_V1=1: keep the one-read-per-lane kernel (A/B runs)
     std::string err;
 };
 
@@ -304,7 +541,8 @@ static int upload_lib(f2q_ctx *c)
     L.n_features = c->ix.n_features;
     L.n_irregular = c->ix.n_irregular;
     memcpy(L.grp, c->ix.grp, sizeof L.grp);
-    uint64_t *tk; uint32_t *ti; uint8_t *fb; uint32_t *fo; uint32_t *ir; uint64_t *gk;
+    L.pk = c->ix.pk;
+    uint64_t *tk; uint32_t *ti; uint8_t *fb; uint32_t *fo; uint32_t *ir; uint64_t *gk; uint64_t *pt;
     int rc;
     if ((rc = dev_upload(c, c->ix.tab_keys.data(), c->ix.tab_keys.size(), &tk, c->lib_allocs))) return rc;
     if ((rc = dev_upload(c, c->ix.tab_idx.data(), c->ix.tab_idx.size(), &ti, c->lib_allocs))) return rc;
@@ -312,6 +550,8 @@ static int upload_lib(f2q_ctx *c)
     if ((rc = dev_upload(c, c->ix.feat_off.data(), c->ix.feat_off.size(), &fo, c->lib_allocs))) return rc;
     if ((rc = dev_upload(c, c->ix.irr_ids.data(), c->ix.irr_ids.size(), &ir, c->lib_allocs))) return rc;
     if ((rc = dev_upload(c, c->ix.key2.data(), c->ix.key2.size(), &gk, c->lib_allocs))) return rc;
+    if ((rc = dev_upload(c, c->ix.ptab.data(), c->ix.ptab.size(), &pt, c->lib_allocs))) return rc;
+    L.ptab = pt;
     L.tab_keys = tk; L.tab_idx = ti; L.feat_bytes = fb; L.feat_off = fo; L.irr_ids = ir;
     c->guide_keys_d = gk;
     LibDev *ld;
@@ -346,6 +586,8 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     for (int i = 0; i < p->n_upstream && i < F2Q_MAX_ITER; i++) c->up_s.push_back(p->upstream[i] ? p->upstream[i] : "");
     for (int i = 0; i < p->n_downstream && i < F2Q_MAX_ITER; i++) c->down_s.push_back(p->downstream[i] ? p->downstream[i] : "");
     c->device = p->device;
+    { const char *fv = getenv("F2Q_FORCE_V1"); c->force_v1 = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
     int rc = setup_run(c);
     if (rc) { g_create_err = c->err; delete c; return rc; }
 #define CREATE_HIP(call)                                                                            \
@@ -367,7 +609,7 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     CREATE_HIP(hipMalloc((void **)&c->run_d, sizeof(RunDev)));
     CREATE_HIP(hipMemcpyAsync(c->run_d, &c->run_h, sizeof(RunDev), hipMemcpyHostToDevice, c->stream));
     // an empty library so that EC mode (and a Counter run before set_features fails cleanly) has valid pointers
-    build_index(c->ix, "", (const uint32_t[]){0}, 0, c->run_h.miss);
+    build_index(c->ix, "", (const uint32_t[]){0}, 0, c->run_h.miss, 0);
     rc = upload_lib(c);
     if (!rc) rc = alloc_acc(c, 0);
     if (rc) { g_create_err = c->err; f2q_destroy(c); return rc; }
@@ -382,6 +624,8 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_all(c->lib_allocs); free_all(c->ec_allocs);
     if (c->acc_d) (void)hipFree(c->acc_d);
+    if (c->slab_d) (void)hipFree(c->slab_d);
+    if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
     if (c->run_d) (void)hipFree(c->run_d);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -397,7 +641,7 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     if (c->prm.mode != 0) return fail(c, F2Q_ESTATE, "Extract+Count mode takes no feature library (fast2q.py:1701)");
     HIPC(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < n; i++) if (offs[i + 1] < offs[i]) return fail(c, F2Q_EINVAL, "offsets must be non-decreasing");
-    build_index(c->ix, seqs ? seqs : "", offs, n, c->run_h.miss);
+    build_index(c->ix, seqs ? seqs : "", offs, n, c->run_h.miss, c->plan.fast_fixed ? c->run_h.length : 0);
     int rc = upload_lib(c);
     if (rc) return rc;
     rc = alloc_acc(c, n);
@@ -491,7 +735,7 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
 static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
 {
     if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
-    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5)};
+    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr};
     if (c->prm.mode == 1 && b->rb.n) {
         // worst case every read inserts a new key made of all its windows
         uint64_t key_bytes = b->dev_bytes;   // upper bound: no key is longer than the read's bytes + separators
@@ -501,13 +745,45 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
     uint32_t launches = 0;
     HIPC(c, hipEventRecord(c->ev_k0, c->stream));
     if (b->pb.n_tiles) {
-        const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * 8u);
         const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
-        if (lds) {
-            size_t shmem = std::max<size_t>(4, (size_t)c->lib_h.n_features * 4);
-            hipLaunchKernelGGL(k_count_fixed<true>, dim3(grid), dim3(F2Q_TILE), shmem, c->stream, c->run_d, c->lib_d, b->pb, acc);
+        const bool v2 = !c->force_v1 && c->lib_h.pk.len == (uint32_t)c->run_h.length && c->lib_h.pk.len > 0 &&
+                        c->lib_h.n_irregular == 0;
+        if (v2) {
+            const uint32_t wgs = (b->pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
+            const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
+            const size_t shmem = (size_t)F2Q_V2_QCAP * 8 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
+            const FixedGeom fg = fixed_geom(c->run_h);
+            const bool spec52 = !c->force_generic && fg.nq == 5 && fg.nb == 2 && c->run_h.thr >= 33;
+            auto kern = lds ? (spec52 ? k_count_fixed4<true, 5, 2> : k_count_fixed4<true, 0, 0>)
+                            : (spec52 ? k_count_fixed4<false, 5, 2> : k_count_fixed4<false, 0, 0>);
+            if (lds) {
+                const size_t need = (size_t)grid * c->lib_h.n_features;
+                if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
+                    if (c->slab_d) (void)hipFree(c->slab_d);
+                    if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
+                    c->slab_d = nullptr; c->slab_n = 0; c->stat_slab_d = nullptr; c->stat_slab_n = 0;
+                    HIPC(c, hipMalloc((void **)&c->slab_d, std::max<size_t>(need, 1) * sizeof(uint32_t)));
+                    HIPC(c, hipMalloc((void **)&c->stat_slab_d, (size_t)grid * 8 * sizeof(unsigned long long)));
+                    c->slab_n = need; c->stat_slab_n = grid;
+                }
+                acc.slab = c->slab_d;
+                acc.stat_slab = c->stat_slab_d;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, b->pb, acc);
+            if (lds && c->lib_h.n_features) {
+                HIPC(c, hipGetLastError());
+                hipLaunchKernelGGL(k_reduce_slabs, dim3((c->lib_h.n_features + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
+                                   c->slab_d, grid, c->lib_h.n_features, acc.counts, c->stat_slab_d, acc.stats);
+                launches++;
+            }
         } else {
-            hipLaunchKernelGGL(k_count_fixed<false>, dim3(grid), dim3(F2Q_TILE), 0, c->stream, c->run_d, c->lib_d, b->pb, acc);
+            const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * 8u);
+            if (lds) {
+                size_t shmem = std::max<size_t>(4, (size_t)c->lib_h.n_features * 4);
+                hipLaunchKernelGGL(k_count_fixed<true>, dim3(grid), dim3(F2Q_TILE), shmem, c->stream, c->run_d, c->lib_d, b->pb, acc);
+            } else {
+                hipLaunchKernelGGL(k_count_fixed<false>, dim3(grid), dim3(F2Q_TILE), 0, c->stream, c->run_d, c->lib_d, b->pb, acc);
+            }
         }
         HIPC(c, hipGetLastError());
         launches++;

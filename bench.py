@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--workload", default="cfg3_50M_10k_m1", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miss", type=int, default=None, help="override --m (experiments)")
+    ap.add_argument("--phred", type=int, default=30, help="override --ph (experiments)")
+    ap.add_argument("--read-len", type=int, default=150, help="override the read length (experiments)")
+    ap.add_argument("--p-n", type=float, default=0.005, help="share of reads with an N in the window (experiments)")
     a = ap.parse_args()
 
     import torch
@@ -70,10 +74,12 @@ def main():
     w = dict(WORKLOADS[a.workload])
     if a.reads:
         w["n_reads"] = a.reads
+    if a.miss is not None:
+        w["miss"] = a.miss
     guides = pkg.binding.synth_library(w["lib_seed"], w["n_guides"], 20)
-    c = pkg.Counter(features=guides, miss=w["miss"], phred=30, length=20, start="0", device=local)
+    c = pkg.Counter(features=guides, miss=w["miss"], phred=a.phred, length=20, start="0", device=local)
     n = w["n_reads"]
-    blk = c.synth_create(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=150)
+    blk = c.synth_create(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=a.read_len, p_n=a.p_n)
     info = blk.info()
 
     # the device accumulator as a torch tensor, so RCCL can all-reduce it in place
@@ -118,8 +124,8 @@ def main():
             "value": total_reads / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (2-bit packed bases) / u8 qualities", "data": "synthetic",
-            "config": {"workload": a.workload, "reads_per_gpu": n, "read_len": 150, "guides": w["n_guides"],
-                       "guide_len": 20, "miss": w["miss"], "phred": 30, "start": 0,
+            "config": {"workload": a.workload, "reads_per_gpu": n, "read_len": a.read_len, "guides": w["n_guides"],
+                       "guide_len": 20, "miss": w["miss"], "phred": a.phred, "start": 0,
                        "general_path_reads_per_gpu": info["n_general"], "sharding": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

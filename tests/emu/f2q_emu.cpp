@@ -20,7 +20,8 @@ struct Emu {
     RunDev run; PackPlan plan; HostIndex ix; LibDev lib;
     std::vector<unsigned long long> acc;      // counts + 5 stats
     EcDev ec; std::vector<unsigned long long> slots, ent_off, ent_count, ent_first, ctr; std::vector<uint32_t> ent_len, arena;
-    uint64_t reads_seen = 0, fast = 0, general = 0;
+    uint64_t reads_seen = 0, fast = 0, general = 0, v2_reads = 0;
+    int use_v2 = 1;
     std::string err;
 };
 
@@ -29,6 +30,7 @@ static void bind_lib(Emu *e)
     LibDev &L = e->lib;
     L.n_features = e->ix.n_features; L.n_irregular = e->ix.n_irregular;
     L.tab_keys = e->ix.tab_keys.data(); L.tab_idx = e->ix.tab_idx.data();
+    L.ptab = e->ix.ptab.data(); L.pk = e->ix.pk;
     L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
     memcpy(L.grp, e->ix.grp, sizeof L.grp);
     e->acc.assign(e->ix.n_features + 5, 0);
@@ -42,7 +44,7 @@ void *emu_create(const f2q_params *p)
     if (fill_run(*p, e->run, e->err)) { delete e; return nullptr; }
     e->plan = make_plan(e->run);
     uint32_t z = 0;
-    build_index(e->ix, "", &z, 0, e->run.miss);
+    build_index(e->ix, "", &z, 0, e->run.miss, 0);
     bind_lib(e);
     const size_t cap = 1 << 16, slots = 1 << 18;
     e->slots.assign(slots, 0); e->ent_off.assign(cap, 0); e->ent_len.assign(cap, 0); e->ent_count.assign(cap, 0);
@@ -57,7 +59,7 @@ void emu_destroy(void *h) { delete (Emu *)h; }
 void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t n)
 {
     Emu *e = (Emu *)h;
-    build_index(e->ix, seqs, offs, n, e->run.miss);
+    build_index(e->ix, seqs, offs, n, e->run.miss, e->plan.fast_fixed ? e->run.length : 0);
     bind_lib(e);
 }
 
@@ -69,10 +71,45 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
     size_t used = frame_fastq(buf, n, recs);
     HostPacked hp;
     pack_records(e->plan, recs, hp);
-    Accum acc{e->acc.data(), e->acc.data() + e->ix.n_features};
+    Accum acc{e->acc.data(), e->acc.data() + e->ix.n_features, nullptr, nullptr};
     PackedBlock pb{};
     pb.n_tiles = hp.n_tiles; pb.wb = hp.wb; pb.wq = hp.wq; pb.rmax = hp.rmax; pb.n_slots = (uint64_t)hp.n_tiles * F2Q_TILE;
     pb.bases = hp.bases.data(); pb.qual = hp.qual.data(); pb.len = hp.len.data();
+    const bool v2 = e->use_v2 && e->lib.pk.len == (uint32_t)e->run.length && e->lib.pk.len > 0 && e->lib.n_irregular == 0;
+    if (v2) {
+        // the v2 kernel's per-lane sequence: 4 reads per lane from 16-byte row loads, packed tables
+        const FixedGeom g = fixed_geom(e->run);
+        const int need = g.st + g.L;
+        for (uint32_t t = 0; t < hp.n_tiles; t++)
+            for (uint32_t lane = 0; lane < 64; lane++) {
+                U4 b[F2Q_MAXBROWS]; uint32_t bad[4] = {0, 0, 0, 0};
+                const uint32_t *qp = pb.qual + ((uint64_t)t * pb.wq + g.qw0) * F2Q_TILE + 4 * lane;
+                const uint32_t *bp = pb.bases + ((uint64_t)t * pb.wb + g.bw0) * F2Q_TILE + 4 * lane;
+                for (int r = 0; r < F2Q_MAXBROWS; r++) {
+                    if (r < g.nb) { const uint32_t *p = bp + (uint64_t)r * F2Q_TILE; b[r] = U4{p[0], p[1], p[2], p[3]}; }
+                    else b[r] = U4{0, 0, 0, 0};
+                }
+                if (g.add_hi)
+                    for (int r = 0; r < F2Q_MAXQROWS; r++)
+                        if (r < g.nq) { const uint32_t *p = qp + (uint64_t)r * F2Q_TILE; fixed4_qrow(g, r, U4{p[0], p[1], p[2], p[3]}, bad); }
+                for (int j = 0; j < 4; j++) {
+                    uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
+                    int res; uint32_t idx = 0;
+                    if (l == F2Q_LEN_SKIP) res = R_SKIP;
+                    else if ((int)l < need || g.L < 1) res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
+                    else if (bad[j]) res = R_QFAIL;
+                    else {
+                        uint64_t key = fixed4_key(g, b, j);
+                        int ex = packed_exact(e->lib, key);
+                        if (ex >= 0) { res = R_PERFECT; idx = (uint32_t)ex; }
+                        else if (e->run.miss > 0) res = packed_near_decide(e->run, e->lib, key, idx);
+                        else res = R_NONALIGNED;
+                    }
+                    if (res == 1 || res == 2) acc.counts[idx]++;
+                    if (res) { acc.stats[0]++; acc.stats[res]++; e->v2_reads++; }
+                }
+            }
+    } else
     for (uint32_t t = 0; t < hp.n_tiles; t++)
         for (uint32_t lane = 0; lane < F2Q_TILE; lane++) {
             uint32_t idx = 0;
@@ -99,6 +136,8 @@ void emu_read_counts(void *h, int64_t *counts, int64_t *stats, uint64_t *fast, u
 }
 
 void emu_set_read_base(void *h, uint64_t b) { ((Emu *)h)->reads_seen = b; }
+void emu_use_v2(void *h, int on) { ((Emu *)h)->use_v2 = on; }
+uint64_t emu_v2_reads(void *h) { return ((Emu *)h)->v2_reads; }
 uint64_t emu_ec_n(void *h) { return ((Emu *)h)->ctr[0]; }
 uint64_t emu_ec_overflow(void *h) { return ((Emu *)h)->ctr[2]; }
 void emu_ec_get(void *h, uint64_t e_, char *key, uint32_t *len, int64_t *count, uint64_t *first)

@@ -40,6 +40,9 @@ def lib():
         L.emu_read_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64)]
         L.emu_set_read_base.argtypes = [vp, C.c_uint64]
+        L.emu_use_v2.argtypes = [vp, C.c_int]
+        L.emu_v2_reads.restype = C.c_uint64
+        L.emu_v2_reads.argtypes = [vp]
         L.emu_ec_n.restype = C.c_uint64
         L.emu_ec_n.argtypes = [vp]
         L.emu_ec_overflow.restype = C.c_uint64
@@ -53,11 +56,12 @@ def lib():
 
 
 class Emu:
-    def __init__(self, features=None, **params):
+    def __init__(self, features=None, v2=True, **params):
         self._p, self._keep = binding.make_params(**params)
         self._h = C.c_void_p(lib().emu_create(C.byref(self._p)))
         if not self._h:
             raise ValueError("emu_create failed")
+        lib().emu_use_v2(self._h, 1 if v2 else 0)
         self.n = 0
         if features is not None:
             enc = [s.encode("latin-1") for s in features]
@@ -69,6 +73,9 @@ class Emu:
 
     def count_block(self, data):
         return lib().emu_count_block(self._h, data, len(data))
+
+    def v2_reads(self):
+        return lib().emu_v2_reads(self._h)
 
     def read(self):
         counts = (C.c_int64 * max(self.n, 1))()

@@ -120,3 +120,35 @@ def test_error_paths(P):
         assert c.count_block(b"") == 0
         assert c.count_block(b"@r\nACGT\n+\n") == 0            # partial record: nothing consumed
         assert list(c.read_counts()[1]) == [0, 0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("force_v1", ["0", "1"], ids=["v2", "v1"])
+@pytest.mark.parametrize("start,length", [(0, 20), (3, 20), (13, 17), (15, 31), (16, 16), (1, 1), (30, 5), (2, 0)])
+def test_window_geometry_sweep_gpu(P, monkeypatch, start, length, force_v1):
+    """every alignment of the window against the tile word grid, clipped reads, both fast kernels"""
+    monkeypatch.setenv("F2Q_FORCE_V1", force_v1)
+    glen = max(length, 1)
+    guides = synth.make_library(min(200, 4 ** glen), glen, 500 + start)
+    spec = synth.Spec(seed=start * 31 + length, n_reads=3000, read_len=start + glen + 3, start=start, p_lowq=0.2)
+    fq = synth.make_fastq(spec, guides) + synth.make_fastq(synth.Spec(seed=77, n_reads=100, read_len=start + glen - 1,
+                                                                        start=max(0, start - 1)), guides)
+    kw = dict(miss=1, length=length, start=str(start))
+    orc = O.Oracle(features=[(f"g{i}", s) for i, s in enumerate(guides)], **kw)
+    orc.count_fastq(fq)
+    with P.Counter(features=guides, **kw) as c:
+        c.count_block(fq)
+        counts, stats = c.read_counts()
+        assert list(stats) == orc.stats() and list(counts) == orc.counts()
+
+
+def test_all_reads_miss_fills_the_queue(P):
+    """a library unrelated to the reads: every quality-passing read goes through the LDS ring"""
+    guides = P.binding.synth_library(1, 5000, 20)
+    other = P.binding.synth_library(2, 5000, 20)
+    with P.Counter(features=other, miss=2) as gen:
+        fq = bytes(gen.synth_fastq(seed=3, n_reads=300000, read_len=40))
+    orc = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(guides)], miss=2)
+    with P.Counter(features=guides, miss=2) as c:
+        c.count_block(fq)
+        counts, stats = c.read_counts()
+        assert list(stats) == orc.stats() and list(counts) == orc.counts()

@@ -21,10 +21,11 @@ def params_of(case):
                 qual_down=p.get("qual_down", 30))
 
 
+@pytest.mark.parametrize("v2", [True, False], ids=["v2", "v1"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_lane_logic_matches_reference(case):
+def test_lane_logic_matches_reference(case, v2):
     feats = loader_view(case["features"]) if case["features"] is not None else None
-    e = Emu(features=[s for _, s in feats] if feats is not None else None, **params_of(case))
+    e = Emu(features=[s for _, s in feats] if feats is not None else None, v2=v2, **params_of(case))
     e.count_block(case_fastq(case))
     counts, stats, fast, gen = e.read()
     exp = case["expected"]
@@ -44,6 +45,7 @@ def test_fast_path_is_exercised():
     e.count_block(case_fastq(case))
     _, stats, fast, gen = e.read()
     assert fast > 0.98 * stats[0] and gen < 0.02 * stats[0] and gen > 0   # reads with 'N' in the window
+    assert e.v2_reads() == fast                                           # ... and through the v2 (4 reads/lane) logic
 
 
 def test_host_generator_matches_spec():
@@ -56,9 +58,10 @@ def test_host_generator_matches_spec():
         assert e.synth_fastq(17, 23, **kw) == synth.make_fastq(synth.Spec(**kw), guides, 17, 23)
 
 
+@pytest.mark.parametrize("v2", [True, False], ids=["v2", "v1"])
 @pytest.mark.parametrize("miss", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("glen,n_guides", [(20, 500), (9, 300), (31, 200), (3, 40), (1, 4)])
-def test_pigeonhole_vs_oracle_dense(miss, glen, n_guides):
+@pytest.mark.parametrize("glen,n_guides", [(20, 500), (9, 300), (31, 200), (28, 300), (3, 40), (1, 4)])
+def test_pigeonhole_vs_oracle_dense(miss, glen, n_guides, v2):
     # dense random libraries + heavy mutation so that ties and multi-piece duplicates are common
     n_guides = min(n_guides, 4 ** glen)
     guides = synth.make_library(n_guides, glen, 1000 + glen)
@@ -67,7 +70,25 @@ def test_pigeonhole_vs_oracle_dense(miss, glen, n_guides):
     kw = dict(miss=miss, length=glen, start="4")
     o = O.Oracle(features=[(f"g{i}", s) for i, s in enumerate(guides)], **kw)
     o.count_fastq(fq)
-    e = Emu(features=guides, **kw)
+    e = Emu(features=guides, v2=v2, **kw)
     e.count_block(fq)
     counts, stats, _, _ = e.read()
     assert stats == o.stats() and counts == o.counts()
+
+
+@pytest.mark.parametrize("start,length", [(0, 20), (3, 20), (13, 17), (15, 31), (16, 16), (1, 1), (30, 5), (2, 0)])
+def test_window_geometry_sweep(start, length):
+    # every alignment of the window against the 16-base / 4-quality word grid, plus clipped reads
+    glen = max(length, 1)
+    guides = synth.make_library(min(200, 4 ** glen), glen, 500 + start)
+    spec = synth.Spec(seed=start * 31 + length, n_reads=1200, read_len=start + glen + 3, start=start, p_lowq=0.2)
+    fq = synth.make_fastq(spec, guides) + synth.make_fastq(synth.Spec(seed=77, n_reads=100, read_len=start + glen - 1,
+                                                                        start=max(0, start - 1)), guides)
+    kw = dict(miss=1, length=length, start=str(start))
+    o = O.Oracle(features=[(f"g{i}", s) for i, s in enumerate(guides)], **kw)
+    o.count_fastq(fq)
+    for v2 in (True, False):
+        e = Emu(features=guides, v2=v2, **kw)
+        e.count_block(fq)
+        counts, stats, _, _ = e.read()
+        assert stats == o.stats() and counts == o.counts(), v2
