@@ -23,6 +23,7 @@
 #define F2Q_REG_MAXLEN 31          // longest feature/window handled as a 2-bit u64 key
 #define F2Q_TILE 256               // reads per packed tile (= threads per workgroup)
 #define F2Q_LEN_SKIP 0xFFFFu       // len-plane marker: slot handled by the general path
+#define F2Q_LEN_FLAG 0x8000u       // len-plane bit: the window holds non-ACGT symbols, marked by bit 7 of their quality bytes
 
 namespace f2q {
 
@@ -554,19 +555,22 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
                       uint32_t lane, uint32_t &idx)
 {
     int rlen = (int)pb.rmax;
+    bool flagged = false;
     if (pb.len) {
         uint32_t l = gp(pb.len)[(uint64_t)tile * F2Q_TILE + lane];
         if (l == F2Q_LEN_SKIP) return 0;
-        rlen = (int)l;
+        flagged = (l & F2Q_LEN_FLAG) != 0;
+        rlen = (int)(l & 0x7FFFu);
     }
     const int st = run.start[0];
     int a = st < rlen ? st : rlen;
     int b = (st + run.length) < rlen ? (st + run.length) : rlen;
     const int L = b - a;                                     // clipped window (Python slice, :354)
-    // ---- Phred mask over quality bytes [a,b) ----
-    if (run.thr >= 33 && L > 0) {
+    // ---- Phred mask over quality bytes [a,b); bit 7 of a byte marks a non-ACGT base (flagged reads only) ----
+    uint64_t forced = 0;
+    if ((run.thr >= 33 || flagged) && L > 0) {
         const uint32_t add_lo = 0x5F5F5F5Fu;                                   // +95
-        const uint32_t add_hi = (uint32_t)(127 - run.thr) * 0x01010101u;
+        const uint32_t add_hi = run.thr >= 33 ? (uint32_t)(127 - run.thr) * 0x01010101u : 0u;
         const auto qp = gp(pb.qual) + ((uint64_t)tile * pb.wq) * F2Q_TILE + lane;
         uint32_t bad = 0;
         const int w0 = a >> 2, w1 = (b - 1) >> 2;
@@ -574,7 +578,11 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
             uint32_t m = 0x80808080u;
             if (w == w0) m &= 0xFFFFFFFFu << (8 * (a & 3));
             if (w == w1) m &= 0xFFFFFFFFu >> (8 * (3 - ((b - 1) & 3)));
-            bad |= qfail4(qp[(uint64_t)w * F2Q_TILE], add_lo, add_hi, m);
+            const uint32_t word = qp[(uint64_t)w * F2Q_TILE];
+            if (add_hi) bad |= qfail4(word & 0x7F7F7F7Fu, add_lo, add_hi, m);
+            uint32_t fl = word & m;
+            for (int k = 0; fl && k < 4; k++)
+                if (fl & (0x80u << (8 * k))) forced |= 1ull << (2 * (4 * w + k - a));
         }
         if (bad) return 4;
     }
@@ -590,6 +598,15 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
         key = (lo | (mid << 32)) >> sh;
         if (sh) key |= hi << (64 - sh);
         key &= (L >= 32) ? ~0ull : ((1ull << (2 * L)) - 1ull);
+    }
+    if (forced) {
+        // non-ACGT symbols mismatch every feature (the packer only flags reads when the library is all-ACGT)
+        const int nforced = popc64(forced);
+        if (run.miss == 0 || nforced > run.miss) return 3;
+        MinTrack tf; tf.init(run.miss);
+        lib_near(lib, key, L, forced, tf);
+        if (tf.cnt == 1) { idx = tf.idx; return 2; }
+        return 3;
     }
     if (L < 1) {
         // empty window: the key "" can only match an (irregular) empty feature
@@ -654,16 +671,17 @@ F2Q_HD FixedGeom fixed_geom(const RunDev &run)
 }
 
 // result codes of one read in the v2 kernel
-enum { R_SKIP = 0, R_PERFECT = 1, R_IMPERFECT = 2, R_NONALIGNED = 3, R_QFAIL = 4, R_SLOW = 5, R_NEAR = 6 };
+enum { R_SKIP = 0, R_PERFECT = 1, R_IMPERFECT = 2, R_NONALIGNED = 3, R_QFAIL = 4, R_SLOW = 5, R_NEAR = 6, R_FORCED = 7 };
 
 // Phred test of one quality row for the 4 reads of a lane (bad[j] != 0: read j fails)
 F2Q_HD void fixed4_qrow(const FixedGeom &g, int r, const U4 &q, uint32_t bad[4])
 {
     const uint32_t m = (r == 0) ? g.qm_first : (r == g.nq - 1) ? g.qm_last : 0x80808080u;
-    bad[0] |= qfail4(q.x, g.add_lo, g.add_hi, m);
-    bad[1] |= qfail4(q.y, g.add_lo, g.add_hi, m);
-    bad[2] |= qfail4(q.z, g.add_lo, g.add_hi, m);
-    bad[3] |= qfail4(q.w, g.add_lo, g.add_hi, m);
+    // bit 7 of a byte is the non-ACGT flag, not quality: strip it before the 7-bit SWAR test
+    bad[0] |= qfail4(q.x & 0x7F7F7F7Fu, g.add_lo, g.add_hi, m);
+    bad[1] |= qfail4(q.y & 0x7F7F7F7Fu, g.add_lo, g.add_hi, m);
+    bad[2] |= qfail4(q.z & 0x7F7F7F7Fu, g.add_lo, g.add_hi, m);
+    bad[3] |= qfail4(q.w & 0x7F7F7F7Fu, g.add_lo, g.add_hi, m);
 }
 
 // 2-bit key of read j of a lane from the base rows the lane loaded
@@ -695,14 +713,46 @@ F2Q_HD int packed_exact(const LibDev &lib, uint64_t key)
     }
 }
 
-// pigeonhole search on the packed piece tables (regular query, no forced positions)
-F2Q_HD void packed_near(const LibDev &lib, uint64_t key, MinTrack &t)
+// bit i -> bit 2i
+F2Q_HD uint64_t spread32(uint32_t v)
+{
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+// flag bits (bit 7 of the quality bytes under the window) of read j of a lane -> one bit per window base
+template <int QR>
+F2Q_HD uint32_t fixed4_flags(const FixedGeom &g, const U4 (&q)[QR], int j)
+{
+    uint64_t bits = 0;                       // bit (4r + k) = byte k of row r
+#pragma unroll
+    for (int r = 0; r < QR; r++) {
+        if (r < g.nq) {
+            const uint32_t m = (r == 0) ? g.qm_first : (r == g.nq - 1) ? g.qm_last : 0x80808080u;
+            const uint32_t f = (u4get(q[r], j) & m) >> 7;                       // 0/1 at bits 0, 8, 16, 24
+            bits |= (uint64_t)(((f * 0x00204081u) >> 21) & 0xFu) << (4 * r);    // gathered into a nibble
+        }
+    }
+    return (uint32_t)(bits >> (g.st & 3));
+}
+
+// pigeonhole search on the packed piece tables; forced2 = 2-bit-spaced mask of query positions that
+// mismatch every feature (non-ACGT symbols)
+F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTrack &t)
 {
     const uint32_t ib = lib.pk.ib;
     const uint64_t imask = (1ull << ib) - 1ull;
     const auto ptab = gp(lib.ptab);
+    const int nforced = popc64(forced2);
+    const uint64_t keep = ~(forced2 | (forced2 << 1));
     for (uint32_t p = 0; p < lib.pk.n_pieces; p++) {
         const PackedPiece pd = lib.pk.piece[p];
+        if ((forced2 >> pd.shift) & pd.mask) continue;                       // this piece can never agree
         const uint64_t pv = (key >> pd.shift) & pd.mask;
         const uint32_t m = (1u << pd.bits) - 1u;
         uint32_t s = hash32(pv, pd.bits);
@@ -714,20 +764,22 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, MinTrack &t)
                 bool dup = false;
                 for (uint32_t q = 0; q < p; q++) {
                     const PackedPiece qd = lib.pk.piece[q];
+                    if ((forced2 >> qd.shift) & qd.mask) continue;
                     if (((x >> qd.shift) & qd.mask) == 0) { dup = true; break; }
                 }
-                if (!dup) t.offer(ham2(x), (uint32_t)(v & imask));
+                if (!dup) t.offer(ham2(x & keep) + nforced, (uint32_t)(v & imask));
             }
             s = (s + 1) & m;
         }
     }
 }
 
-// decision for a key whose exact probe missed (the work the v2 kernel queues and compacts)
-F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key, uint32_t &idx)
+// decision for a key whose exact probe missed, or that holds flagged symbols (one bit per base in
+// `forced`): the work the v2 kernel queues and compacts
+F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key, uint32_t forced, uint32_t &idx)
 {
     MinTrack t; t.init(run.miss);
-    packed_near(lib, key, t);
+    packed_near(lib, key, forced ? spread32(forced) : 0ull, t);
     if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? R_PERFECT : R_IMPERFECT; }
     return R_NONALIGNED;
 }

@@ -191,6 +191,7 @@ struct PackPlan {
     bool fast_fixed = false;       // fixed offset, one window, 0 <= length <= 31, Counter mode
     int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
     int from = 0;                  // ... and only [from, need) is ever looked at
+    bool inband_n = false;         // non-ACGT window symbols travel as flag bits (all-ACGT library only)
 };
 
 inline PackPlan make_plan(const RunDev &run)
@@ -212,7 +213,7 @@ inline bool read_is_clean(const PackPlan &pl, const Rec &r)
     if (r.qlen != r.len) return false;
     uint32_t b = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
     for (uint32_t j = (uint32_t)pl.from; j < b; j++) {
-        if (base_code(r.seq[j]) > 3u) return false;
+        if (base_code(up8(r.seq[j])) > 3u && !pl.inband_n) return false;     // the window is upper-cased (:354)
         if (r.qual[j] & 0x80) return false;
     }
     return true;
@@ -260,22 +261,27 @@ inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostP
         const Rec &r = recs[clean[s]];
         const size_t tile = s / F2Q_TILE, lane = s % F2Q_TILE;
         const uint32_t l = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
-        hp.len[tile * F2Q_TILE + lane] = (uint16_t)l;
+        bool flagged = false;
+        for (uint32_t j = (uint32_t)pl.from; j < l; j++) flagged |= base_code(up8(r.seq[j])) > 3u;
+        hp.len[tile * F2Q_TILE + lane] = (uint16_t)(l | (flagged ? F2Q_LEN_FLAG : 0u));
         uint32_t *bp = hp.bases.data() + tile * hp.wb * F2Q_TILE + lane;
         uint32_t *qp = hp.qual.data() + tile * hp.wq * F2Q_TILE + lane;
         for (uint32_t w = 0; w * 16 < l; w++) {
             uint32_t v = 0;
             for (uint32_t j = 0; j < 16 && w * 16 + j < l; j++) {
-                uint32_t c = base_code(r.seq[w * 16 + j]);          // outside the window anything may occur:
-                v |= (c > 3u ? 0u : c) << (2 * j);                  // it is never looked at, store 'A'
+                uint32_t c = base_code(up8(r.seq[w * 16 + j]));     // non-ACGT: stored as 'A'; inside the window it is
+                v |= (c > 3u ? 0u : c) << (2 * j);                  // flagged below, outside it is never looked at
             }
             bp[(size_t)w * F2Q_TILE] = v;
         }
         for (uint32_t w = 0; w * 4 < l; w++) {
             uint32_t v = 0;
             for (uint32_t j = 0; j < 4 && w * 4 + j < l; j++) {
-                uint32_t q = r.qual[w * 4 + j];
-                v |= (q & 0x80u ? 0u : q) << (8 * j);               // keep every stored byte 7-bit (SWAR)
+                const uint32_t pos = w * 4 + j;
+                uint32_t q = r.qual[pos];
+                q = (q & 0x80u) ? 0u : q;                           // keep every stored byte 7-bit (SWAR)
+                if (pos >= (uint32_t)pl.from && base_code(up8(r.seq[pos])) > 3u) q |= 0x80u;   // flag bit
+                v |= q << (8 * j);
             }
             qp[(size_t)w * F2Q_TILE] = v;
         }

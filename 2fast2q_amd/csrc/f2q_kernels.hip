@@ -103,7 +103,7 @@ __global__ __launch_bounds__(F2Q_TILE) void k_count_fixed(const RunDev *__restri
 // ring; once a workgroup's ring holds a full workgroup of keys they are searched one per lane.
 #define F2Q_V2_THREADS 512
 #define F2Q_V2_WAVES (F2Q_V2_THREADS / 64)
-#define F2Q_V2_QCAP 4096u
+#define F2Q_V2_QCAP 320u      // entries per wave ring: < 64 left over + <= 256 pushed per tile
 
 template <bool NT>
 __device__ __forceinline__ U4 ld_u4(const uint32_t F2Q_GLOBAL *p)
@@ -119,30 +119,35 @@ __device__ __noinline__ int slow_read(const RunDev *run, const LibDev *lib, cons
 {
     return fixed_lane(*run, *lib, *pb, tile, slot, *idx);
 }
-__device__ __noinline__ int near_read(const RunDev *run, const LibDev *lib, uint64_t key, uint32_t *idx)
+__device__ __noinline__ int near_read(const RunDev *run, const LibDev *lib, uint64_t key, uint32_t forced, uint32_t *idx)
 {
-    return packed_near_decide(*run, *lib, key, *idx);
+    return packed_near_decide(*run, *lib, key, forced, *idx);
 }
 
 // NQ / NB: number of quality / base rows under the window when known at compile time (the common
 // geometries get their own instantiation so that all row loads sit in one basic block and issue
 // back to back); 0 = run-time geometry, rows beyond the window are clamped re-loads of the last one.
 template <bool USE_LDS, int NQ, int NB>
-__global__ __launch_bounds__(F2Q_V2_THREADS) void k_count_fixed4(const RunDev *__restrict__ runp,
+// launch bound 4 waves/SIMD = two 512-thread workgroups per CU
+__global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev *__restrict__ runp,
                                                                   const LibDev *__restrict__ libp, PackedBlock pb,
                                                                   Accum acc)
 {
     extern __shared__ unsigned long long smem64[];
-    unsigned long long *queue = smem64;                                   // F2Q_V2_QCAP keys
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_QCAP);  // n_features counters (USE_LDS)
-    __shared__ uint32_t q_head, q_tail;
+    // one ring of keys per wave: pushes and drains are wave-synchronous, so the tile loop has no barrier
+    unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;                 // keys
+    uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + (threadIdx.x >> 6) * F2Q_V2_QCAP;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + F2Q_V2_WAVES * F2Q_V2_QCAP;  // USE_LDS
+    __shared__ uint32_t q_tails[F2Q_V2_WAVES];
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
     const uint32_t nf = lib.n_features;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (USE_LDS) for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) hist[i] = 0;
-    if (tid == 0) { q_head = 0; q_tail = 0; }
+    if (tid < F2Q_V2_WAVES) q_tails[tid] = 0;
     __syncthreads();
+    uint32_t *q_tail = &q_tails[wave];
+    uint32_t q_head = 0;
     const FixedGeom g = fixed_geom(run);
     const int need = g.st + g.L;
     const bool do_near = run.miss > 0;
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_count_fixed4(const RunDev *_
         const uint32_t tile = base + wave;
         int res[4] = {R_SKIP, R_SKIP, R_SKIP, R_SKIP};
         uint64_t key[4] = {0, 0, 0, 0};
+        uint32_t forced[4] = {0, 0, 0, 0};
         if (tile < pb.n_tiles) {
             constexpr int QR = NQ ? NQ : F2Q_MAXQROWS, BR = NB ? NB : F2Q_MAXBROWS;
             constexpr bool NT = true;                    // tile rows are streamed once: keep L2 for the tables
@@ -174,11 +180,16 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_count_fixed4(const RunDev *_
                 row = row < pb.wb ? row : pb.wb - 1u;       // reads shorter than the window: stay inside the tile
                 brow[r] = ld_u4<NT>(bp + (uint64_t)row * F2Q_TILE);
             }
+            if (NQ || g.add_hi) {                        // --ph <= 1: no quality row is needed at all
 #pragma unroll
-            for (int r = 0; r < QR; r++) {
-                uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0)));
-                row = row < pb.wq ? row : pb.wq - 1u;
-                qrow[r] = ld_u4<NT>(qp + (uint64_t)row * F2Q_TILE);
+                for (int r = 0; r < QR; r++) {
+                    uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0)));
+                    row = row < pb.wq ? row : pb.wq - 1u;
+                    qrow[r] = ld_u4<NT>(qp + (uint64_t)row * F2Q_TILE);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < QR; r++) qrow[r] = U4{0, 0, 0, 0};
             }
             uint32_t len01 = 0, len23 = 0;
             if (pb.len) {
@@ -195,10 +206,17 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_count_fixed4(const RunDev *_
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+                const bool have_q = NQ || g.add_hi;            // the flag bits travel in the quality rows
                 if (l == F2Q_LEN_SKIP) res[j] = R_SKIP;
-                else if ((int)l < need || g.L < 1) res[j] = R_SLOW;
+                else if ((int)(l & 0x7FFFu) < need || g.L < 1 || ((l & F2Q_LEN_FLAG) && !have_q)) res[j] = R_SLOW;
                 else if (bad[j]) res[j] = R_QFAIL;
-                else { res[j] = R_NEAR; key[j] = fixed4_key(g, brow, j); }
+                else {
+                    res[j] = R_NEAR; key[j] = fixed4_key(g, brow, j);
+                    if (l & F2Q_LEN_FLAG) {                    // non-ACGT symbols in the window (rare)
+                        forced[j] = fixed4_flags(g, qrow, j);
+                        if (forced[j]) res[j] = (!do_near || __popc(forced[j]) > run.miss) ? R_NONALIGNED : R_FORCED;
+                    }
+                }
             }
             // exact probes: up to 4 reads x 2 slots in flight per lane
             uint32_t s[4]; bool pend[4];
@@ -230,36 +248,38 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_count_fixed4(const RunDev *_
                     res[j] = r1;
                 } else if (res[j] == R_NEAR) {
                     if (do_near) npush++; else res[j] = R_NONALIGNED;
-                }
+                } else if (res[j] == R_FORCED) npush++;
                 st0 += (res[j] != R_SKIP); st1 += (res[j] == R_PERFECT); st2 += (res[j] == R_IMPERFECT);
                 st3 += (res[j] == R_NONALIGNED); st4 += (res[j] == R_QFAIL);
             }
             if (npush) {
-                uint32_t at = atomicAdd(&q_tail, npush);
+                uint32_t at = atomicAdd(q_tail, npush);
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (res[j] == R_NEAR) { queue[at % F2Q_V2_QCAP] = key[j]; at++; }
+                for (int j = 0; j < 4; j++)
+                    if (res[j] == R_NEAR || res[j] == R_FORCED) {
+                        queue[at % F2Q_V2_QCAP] = key[j]; qforced[at % F2Q_V2_QCAP] = forced[j]; at++;
+                    }
             }
         }
         if (do_near) {
-            __syncthreads();
-            uint32_t head = q_head;
-            const uint32_t tail = q_tail;
-            while (tail - head >= F2Q_V2_THREADS) {
+            // LDS operations of one wave complete in order; the fence keeps the compiler from moving the reads up
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+            while (tail - q_head >= 64u) {
                 uint32_t idx = 0;
-                int r = near_read(runp, libp, queue[(head + tid) % F2Q_V2_QCAP], &idx);
+                int r = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
                 if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
-                head += F2Q_V2_THREADS;
+                q_head += 64u;
             }
-            __syncthreads();
-            if (tid == 0) q_head = head;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
     if (do_near) {
-        __syncthreads();
-        const uint32_t head = q_head, tail = q_tail;
-        if (tid < tail - head) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+        if (lane < tail - q_head) {
             uint32_t idx = 0;
-            int r = near_read(runp, libp, queue[(head + tid) % F2Q_V2_QCAP], &idx);
+            int r = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
             if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
         }
     }
@@ -373,7 +393,7 @@ struct SynthOut {
     uint8_t *raw; unsigned long long *off; uint32_t *glen, *gqlen, *gindex;
     unsigned long long *g_count; unsigned long long g_cap;
     int all_general;           // 1: every read is written as a raw record
-    int window_only_clean;     // 1: only the window decides cleanliness (fixed mode)
+    int inband_n;              // 1: an 'N' inside the window is flagged in place instead of taking the general path
 };
 
 __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *__restrict__ guide_keys, SynthOut o,
@@ -388,10 +408,8 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
     const int R = s.read_len;
     // does the read hold a symbol the packed planes cannot carry?  (only 'N' is ever generated)
     bool dirty = o.all_general != 0;
-    if (!dirty && r.n_pos >= 0) {
-        int p = r.wstart + r.n_pos;
-        dirty = p < R;
-    }
+    const int npos = (r.n_pos >= 0 && r.wstart + r.n_pos < R) ? r.wstart + r.n_pos : -1;
+    if (!dirty && npos >= 0 && !o.inband_n) dirty = true;
     if (dirty) {
         if (o.len) o.len[slot] = (uint16_t)F2Q_LEN_SKIP;
         unsigned long long g = atomicAdd(o.g_count, 1ull);
@@ -408,7 +426,7 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
         // the packed slot stays zero-filled and is skipped through the len plane
         return;
     }
-    if (o.len) o.len[slot] = (uint16_t)R;
+    if (o.len) o.len[slot] = (uint16_t)((uint32_t)R | (npos >= 0 ? F2Q_LEN_FLAG : 0u));
     uint32_t *bp = o.bases + (tile * o.wb) * F2Q_TILE + lane;
     uint32_t *qp = o.qual + (tile * o.wq) * F2Q_TILE + lane;
     uint64_t fw = 0;
@@ -418,7 +436,7 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
         uint8_t c = synth_base(s, r, p, fw);
         uint32_t code = base_code(c); if (code > 3u) code = 0;
         bw |= code << (2 * (p & 15));
-        qw |= (uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') << (8 * (p & 3));
+        qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * (p & 3));
         if ((p & 15) == 15 || p == R - 1) { bp[(uint64_t)(p >> 4) * F2Q_TILE] = bw; bw = 0; }
         if ((p & 3) == 3 || p == R - 1) { qp[(uint64_t)(p >> 2) * F2Q_TILE] = qw; qw = 0; }
     }
@@ -646,6 +664,7 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     if (rc) return rc;
     rc = alloc_acc(c, n);
     if (rc) return rc;
+    c->plan.inband_n = c->plan.fast_fixed && c->ix.n_irregular == 0;
     c->have_lib = true;
     return F2Q_OK;
 }
@@ -751,7 +770,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         if (v2) {
             const uint32_t wgs = (b->pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
-            const size_t shmem = (size_t)F2Q_V2_QCAP * 8 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
+            const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
             const FixedGeom fg = fixed_geom(c->run_h);
             const bool spec52 = !c->force_generic && fg.nq == 5 && fg.nb == 2 && c->run_h.thr >= 33;
             auto kern = lds ? (spec52 ? k_count_fixed4<true, 5, 2> : k_count_fixed4<true, 0, 0>)
@@ -1062,6 +1081,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
     const bool fast = c->plan.fast_fixed;
     SynthOut o; memset(&o, 0, sizeof o);
     o.all_general = fast ? 0 : 1;
+    o.inband_n = c->plan.inband_n ? 1 : 0;
     const uint64_t n_tiles = (s->n_reads + F2Q_TILE - 1) / F2Q_TILE;
     const uint64_t n_slots = n_tiles * F2Q_TILE;
     // general-path capacity: everything, or the expected 'N' share with a wide margin

@@ -59,3 +59,18 @@ def pkg():
 @pytest.fixture(scope="session")
 def cases():
     return load_cases()
+
+
+def sprinkle_symbols(fastq, seed, rate=0.08, symbols=b"NnRacgtY."):
+    """Rewrite random bases of a FASTQ buffer with lower-case / N / IUPAC / junk symbols (sequence lines only)."""
+    import random
+    rng = random.Random(seed)
+    lines = fastq.split(b"\n")
+    for i in range(1, len(lines), 4):
+        b = bytearray(lines[i])
+        for j in range(len(b)):
+            if rng.random() < rate:
+                c = symbols[rng.randrange(len(symbols))]
+                b[j] = ord(chr(b[j]).lower()) if c in b"acgt" and rng.random() < 0.5 else c
+        lines[i] = bytes(b)
+    return b"\n".join(lines)

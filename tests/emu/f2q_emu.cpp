@@ -61,6 +61,7 @@ void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t 
     Emu *e = (Emu *)h;
     build_index(e->ix, seqs, offs, n, e->run.miss, e->plan.fast_fixed ? e->run.length : 0);
     bind_lib(e);
+    e->plan.inband_n = e->plan.fast_fixed && e->ix.n_irregular == 0;
 }
 
 // the same two-stream split the library does: packed tiles through fixed_lane, the rest through general_read
@@ -82,28 +83,43 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
         const int need = g.st + g.L;
         for (uint32_t t = 0; t < hp.n_tiles; t++)
             for (uint32_t lane = 0; lane < 64; lane++) {
-                U4 b[F2Q_MAXBROWS]; uint32_t bad[4] = {0, 0, 0, 0};
-                const uint32_t *qp = pb.qual + ((uint64_t)t * pb.wq + g.qw0) * F2Q_TILE + 4 * lane;
-                const uint32_t *bp = pb.bases + ((uint64_t)t * pb.wb + g.bw0) * F2Q_TILE + 4 * lane;
+                U4 b[F2Q_MAXBROWS], qr[F2Q_MAXQROWS]; uint32_t bad[4] = {0, 0, 0, 0};
+                const uint32_t *qp = pb.qual + ((uint64_t)t * pb.wq) * F2Q_TILE + 4 * lane;
+                const uint32_t *bp = pb.bases + ((uint64_t)t * pb.wb) * F2Q_TILE + 4 * lane;
+                const bool have_q = g.add_hi != 0;
                 for (int r = 0; r < F2Q_MAXBROWS; r++) {
-                    if (r < g.nb) { const uint32_t *p = bp + (uint64_t)r * F2Q_TILE; b[r] = U4{p[0], p[1], p[2], p[3]}; }
-                    else b[r] = U4{0, 0, 0, 0};
+                    uint32_t row = g.bw0 + (r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
+                    row = row < pb.wb ? row : pb.wb - 1;
+                    const uint32_t *p = bp + (uint64_t)row * F2Q_TILE; b[r] = U4{p[0], p[1], p[2], p[3]};
+                }
+                for (int r = 0; r < F2Q_MAXQROWS; r++) {
+                    uint32_t row = g.qw0 + (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
+                    row = row < pb.wq ? row : pb.wq - 1;
+                    const uint32_t *p = qp + (uint64_t)row * F2Q_TILE;
+                    qr[r] = have_q ? U4{p[0], p[1], p[2], p[3]} : U4{0, 0, 0, 0};
                 }
                 if (g.add_hi)
                     for (int r = 0; r < F2Q_MAXQROWS; r++)
-                        if (r < g.nq) { const uint32_t *p = qp + (uint64_t)r * F2Q_TILE; fixed4_qrow(g, r, U4{p[0], p[1], p[2], p[3]}, bad); }
+                        if (r < g.nq) fixed4_qrow(g, r, qr[r], bad);
                 for (int j = 0; j < 4; j++) {
                     uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
                     int res; uint32_t idx = 0;
                     if (l == F2Q_LEN_SKIP) res = R_SKIP;
-                    else if ((int)l < need || g.L < 1) res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
+                    else if ((int)(l & 0x7FFFu) < need || g.L < 1 || ((l & F2Q_LEN_FLAG) && !have_q))
+                        res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
                     else if (bad[j]) res = R_QFAIL;
                     else {
                         uint64_t key = fixed4_key(g, b, j);
-                        int ex = packed_exact(e->lib, key);
-                        if (ex >= 0) { res = R_PERFECT; idx = (uint32_t)ex; }
-                        else if (e->run.miss > 0) res = packed_near_decide(e->run, e->lib, key, idx);
-                        else res = R_NONALIGNED;
+                        uint32_t forced = (l & F2Q_LEN_FLAG) ? fixed4_flags(g, qr, j) : 0u;
+                        if (forced) {
+                            if (e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss) res = R_NONALIGNED;
+                            else res = packed_near_decide(e->run, e->lib, key, forced, idx);
+                        } else {
+                            int ex = packed_exact(e->lib, key);
+                            if (ex >= 0) { res = R_PERFECT; idx = (uint32_t)ex; }
+                            else if (e->run.miss > 0) res = packed_near_decide(e->run, e->lib, key, 0u, idx);
+                            else res = R_NONALIGNED;
+                        }
                     }
                     if (res == 1 || res == 2) acc.counts[idx]++;
                     if (res) { acc.stats[0]++; acc.stats[res]++; e->v2_reads++; }

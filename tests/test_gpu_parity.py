@@ -3,7 +3,7 @@ captured from the reference, and against the oracle on seeded synthetic inputs. 
 import pytest
 
 import synth
-from conftest import case_fastq, load_cases, loader_view, pkg
+from conftest import case_fastq, load_cases, loader_view, pkg, sprinkle_symbols
 from oracle import oracle as O
 from test_lane_logic_cpu import params_of
 
@@ -152,3 +152,18 @@ def test_all_reads_miss_fills_the_queue(P):
         c.count_block(fq)
         counts, stats = c.read_counts()
         assert list(stats) == orc.stats() and list(counts) == orc.counts()
+
+
+@pytest.mark.parametrize("miss", [0, 1, 2])
+def test_odd_symbols_in_the_window_gpu(P, miss):
+    guides = synth.make_library(150, 12, 4242)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=miss, n_reads=20000, read_len=40, start=5, p_sub=0.3), guides), 9)
+    for lib in (guides, guides[:100] + [g[:5] + "N" + g[6:] for g in guides[100:]]):
+        kw = dict(miss=miss, length=12, start="5")
+        o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+        o.count_fastq(fq)
+        with P.Counter(features=lib, **kw) as c:
+            _, t = c.count_block(fq, want_timing=True)
+            counts, stats = c.read_counts()
+            assert list(stats) == o.stats() and list(counts) == o.counts()
+            assert (t["general_reads"] == 0) == (lib is guides)
