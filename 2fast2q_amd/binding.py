@@ -18,7 +18,7 @@ EXPORTS = (
     "f2q_version", "f2q_create", "f2q_destroy", "f2q_last_error", "f2q_set_features", "f2q_count_block",
     "f2q_count_file", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
     "f2q_block_free", "f2q_synth_fastq", "f2q_synth_library", "f2q_reset_counts", "f2q_read_counts",
-    "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base",
+    "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base", "f2q_synth_guides",
 )
 
 ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "EHIP", -4: "ENOMEM", -5: "EIO", -6: "ETRUNCATED", -7: "ESTATE",
@@ -140,6 +140,7 @@ def load(path=None):
     L.f2q_block_free.argtypes = [vp, vp]; L.f2q_block_free.restype = None
     L.f2q_synth_fastq.argtypes = [vp, C.POINTER(Synth), C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_size_t)]
     L.f2q_synth_library.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p]
+    L.f2q_synth_guides.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32]
     L.f2q_reset_counts.argtypes = [vp]
     L.f2q_set_read_base.argtypes = [vp, C.c_uint64]
     L.f2q_read_counts.argtypes = [vp, i64p, i64p]
@@ -269,13 +270,22 @@ class Counter:
         self._check(self._L.f2q_block_from_fastq(self._h, C.cast(buf, C.c_void_p), n, C.byref(h)))
         return Block(self, h)
 
-    def synth_create(self, **spec):
+    def synth_guides(self, guides):
+        """guide set for the synthetic generator (needed by Extract+Count contexts, which take no library)"""
+        glen = len(guides[0])
+        self._check(self._L.f2q_synth_guides(self._h, "".join(guides).encode(), len(guides), glen))
+
+    def synth_create(self, guides=None, **spec):
+        if guides is not None:
+            self.synth_guides(guides)
         s, keep = make_synth(**spec)
         h = C.c_void_p()
         self._check(self._L.f2q_synth_create(self._h, C.byref(s), C.byref(h)))
         return Block(self, h)
 
-    def synth_fastq(self, lo=0, hi=None, **spec):
+    def synth_fastq(self, lo=0, hi=None, guides=None, **spec):
+        if guides is not None:
+            self.synth_guides(guides)
         s, keep = make_synth(**spec)
         hi = s.n_reads if hi is None else hi
         n = C.c_size_t(0)

@@ -55,6 +55,9 @@ struct RunDev {
     int32_t up_len[F2Q_DEV_MAX_ITER], down_len[F2Q_DEV_MAX_ITER];
     uint8_t up[F2Q_DEV_MAX_ITER][F2Q_ANCHOR_MAX];
     uint8_t down[F2Q_DEV_MAX_ITER][F2Q_ANCHOR_MAX];
+    // packed anchored path (one --us/--ds pair, ACGT-only anchors of 1..32 bases): 2-bit codes of pair 0
+    int32_t anchors_packed;            // 1: up2/down2 are valid
+    uint8_t up2[32], down2[32];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -106,8 +109,15 @@ struct EcDev {
     unsigned long long *ent_first;     // min global read index that produced the key
     uint32_t *arena;                   // key bytes, 4 per word, little endian
     unsigned long long arena_words;
-    unsigned long long *ctr;           // [0] n_entries  [1] arena words used  [2] overflow flag
+    unsigned long long *ctr;           // [0] n_entries  [1] arena words used  [2] overflow flag  [3] keys in the u64 table
+    // keys that are plain ACGT strings of <= 29 bases live in a second, single-word table:
+    // slot = (length << 58) | 2-bit key, claimed with one CAS; ~0 = empty
+    unsigned long long *k64_slots;
+    unsigned long long *k64_count;
+    unsigned long long *k64_first;
+    uint32_t k64_mask, k64_pad;
 };
+#define F2Q_EC64_MAXLEN 29
 
 F2Q_HD void acc_add(unsigned long long *p, unsigned long long v)
 {
@@ -489,6 +499,27 @@ F2Q_HD void ec_insert(const EcDev &ec, const KV &kv, unsigned long long read_ind
     F2Q_ST64(&ec.ctr[2], 2ull);                         // probe bound hit: reported as an error
 }
 
+// single-word insert-or-increment for regular keys (see EcDev)
+F2Q_HD void ec64_insert(const EcDev &ec, uint64_t key, int len, unsigned long long read_index)
+{
+    const unsigned long long k = ((unsigned long long)len << 58) | key;
+    uint32_t s = hash32(k ^ (k >> 29), 32) & ec.k64_mask;
+    for (uint32_t guard = 0; guard <= ec.k64_mask; guard++) {
+        unsigned long long v = F2Q_LD64(&ec.k64_slots[s]);
+        if (v == KEY_EMPTY) {
+            v = ec_cas(&ec.k64_slots[s], KEY_EMPTY, k);
+            if (v == KEY_EMPTY) { ec_fetch_add(&ec.ctr[3], 1ull); v = k; }
+        }
+        if (v == k) {
+            ec_fetch_add(&ec.k64_count[s], 1ull);
+            ec_min(&ec.k64_first[s], read_index);
+            return;
+        }
+        s = (s + 1) & ec.k64_mask;
+    }
+    F2Q_ST64(&ec.ctr[2], 3ull);                          // table full: reported as an error by the host
+}
+
 // ---------------------------------------------------------------------------------------------
 // general path: one read given as raw bytes.  st[] = the 5 reference counters (thread-local).
 // ---------------------------------------------------------------------------------------------
@@ -521,7 +552,16 @@ F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, 
             if (res == 1 || res == 2) acc_add(&acc.counts[idx], 1ull);
             st[res]++;
         } else {
-            ec_insert(ec, kv, read_index);
+            // plain ACGT keys of <= 29 bases go to the single-word table (so that a key never sits in both)
+            bool regular = (kv.nseg == 1 && kv.len <= F2Q_EC64_MAXLEN && ec.k64_slots != nullptr);
+            uint64_t key = 0;
+            for (int j = 0; regular && j < kv.len; j++) {
+                uint32_t c = base_code(up8(kv.seq[kv.a[0] + j]));
+                if (c > 3u) regular = false;
+                key |= (uint64_t)(c & 3u) << (2 * j);
+            }
+            if (regular) ec64_insert(ec, key, kv.len, read_index);
+            else ec_insert(ec, kv, read_index);
             st[1]++;                                                             // :387
         }
     }
@@ -537,9 +577,11 @@ struct PackedBlock {
     uint64_t n_slots;          // read slots (multiple of F2Q_TILE; slots >= n_valid hold len = SKIP)
     uint64_t first_index;      // global index of slot 0 (for EC first-occurrence ordering)
     uint32_t n_tiles, wb, wq, rmax;
+    uint32_t planar_nw, pad0;  // > 0: bases are bit-planes of planar_nw words (anchored runs), wb = 2 * planar_nw
     const uint32_t *bases;     // [n_tiles][wb][F2Q_TILE]
     const uint32_t *qual;      // [n_tiles][wq][F2Q_TILE]
     const uint16_t *len;       // [n_tiles][F2Q_TILE] or nullptr (all reads rmax long, none skipped)
+    const uint32_t *index;     // [n_tiles][F2Q_TILE] position of the slot's read inside the block, or nullptr (== slot)
 };
 
 // any byte of the 4 in w (all < 128) inside [33, thr]?  mask selects the bytes to test (0x80 per byte)
@@ -782,6 +824,214 @@ F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key
     packed_near(lib, key, forced ? spread32(forced) : 0ull, t);
     if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? R_PERFECT : R_IMPERFECT; }
     return R_NONALIGNED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast path, anchored (--us / --ds): one lane = one read held as two bit-planes.
+// Planar tile layout (anchored runs): base rows 0..NW-1 hold the LOW bit of 32 bases per word,
+// rows NW..2NW-1 the HIGH bit (A=00 C=01 G=10 T=11; bit i of word w = base 32w+i).
+// The anchor search is bit-parallel over all start positions at once: for anchor symbol j the
+// "differs from this symbol" plane is shifted right by j and added into bit-sliced saturating
+// counters; positions whose count is <= k are hits and the first one is a count-trailing-zeros.
+// ---------------------------------------------------------------------------------------------
+F2Q_HD uint32_t funnel_shr(uint32_t hi, uint32_t lo, int sh)      // (hi:lo) >> sh, 0 <= sh <= 31
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+#else
+    return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+#endif
+}
+F2Q_HD int ctz32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffs((int)x) - 1;
+#else
+    return __builtin_ctz(x);
+#endif
+}
+// bits [lo, hi) of a 32-bit word (arguments may lie outside 0..32)
+F2Q_HD uint32_t range_mask32(int lo, int hi)
+{
+    lo = lo < 0 ? 0 : lo; hi = hi > 32 ? 32 : hi;
+    if (hi <= lo) return 0u;
+    uint32_t upper = hi >= 32 ? ~0u : ((1u << hi) - 1u);
+    return upper & (lo >= 32 ? 0u : (~0u << lo));
+}
+
+// positions p at which an s-symbol anchor (2-bit codes) sits within k mismatches; KB = counter bits
+// (0: exact search, 1: k <= 1, 2: k <= 3, 3: k <= 7)
+template <int NW, int KB>
+F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint8_t *codes, int s, int k,
+                        uint32_t (&hit)[NW])
+{
+    uint32_t cnt[KB > 0 ? KB : 1][NW], ovf[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        ovf[w] = 0;
+#pragma unroll
+        for (int b = 0; b < (KB > 0 ? KB : 1); b++) cnt[b][w] = 0;
+    }
+    for (int j = 0; j < s; j++) {                       // wave-uniform loop
+        const uint32_t la = (codes[j] & 1) ? ~0u : 0u, ha = (codes[j] & 2) ? ~0u : 0u;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t lo = funnel_shr(w + 1 < NW ? LO[w + 1] : 0u, LO[w], j);
+            const uint32_t hi = funnel_shr(w + 1 < NW ? HI[w + 1] : 0u, HI[w], j);
+            uint32_t x = (lo ^ la) | (hi ^ ha);          // 1 = base p+j differs from anchor symbol j
+            if (KB == 0) ovf[w] |= x;
+            else {
+#pragma unroll
+                for (int b = 0; b < KB; b++) { uint32_t c = cnt[b][w] & x; cnt[b][w] ^= x; x = c; }
+                ovf[w] |= x;
+            }
+        }
+    }
+    // hit = count <= k (bit-sliced compare against the wave-uniform k) and no overflow
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint32_t gt = 0, eq = ~0u;
+#pragma unroll
+        for (int b = KB - 1; b >= 0; b--) {
+            if ((k >> b) & 1) eq &= cnt[b][w];
+            else { gt |= eq & cnt[b][w]; eq &= ~cnt[b][w]; }
+        }
+        hit[w] = ~gt & ~ovf[w];
+    }
+}
+
+// first set bit at a position in [from, to] (inclusive) or -1
+template <int NW>
+F2Q_HD int first_hit(const uint32_t (&hit)[NW], int from, int to)
+{
+    int pos = -1;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; w--) {
+        const uint32_t m = hit[w] & range_mask32(from - 32 * w, to + 1 - 32 * w);
+        if (m) pos = 32 * w + ctz32(m);
+    }
+    return pos;
+}
+
+// any set bit of F in [a, b)
+template <int NW>
+F2Q_HD bool any_in_range(const uint32_t (&F)[NW], int a, int b)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) acc |= F[w] & range_mask32(a - 32 * w, b - 32 * w);
+    return acc != 0;
+}
+
+// L (<= 32) bits of a plane starting at bit `start`
+template <int NW>
+F2Q_HD uint32_t plane_extract(const uint32_t (&P)[NW], int start, int L)
+{
+    const int wi = start >> 5;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        if (w == wi) lo = P[w];
+        if (w == wi + 1) hi = P[w];
+    }
+    const uint32_t v = funnel_shr(hi, lo, start & 31);
+    return L >= 32 ? v : (v & ((1u << L) - 1u));
+}
+
+// per-base Phred fail vector from NQ quality words (4 bytes each, all < 128): bit i = byte i fails thr
+template <int NW, int NQW>
+F2Q_HD void fail_vector(const uint32_t (&Q)[NQW], int thr, uint32_t (&F)[NW])
+{
+#pragma unroll
+    for (int w = 0; w < NW; w++) F[w] = 0;
+    if (thr < 33) return;
+    const uint32_t add_lo = 0x5F5F5F5Fu, add_hi = (uint32_t)(127 - thr) * 0x01010101u;
+#pragma unroll
+    for (int i = 0; i < NQW; i++) {
+        if (i / 8 < NW) {
+            const uint32_t f = qfail4(Q[i], add_lo, add_hi, 0x80808080u) >> 7;      // 0/1 at bits 0, 8, 16, 24
+            F[i / 8] |= (((f * 0x00204081u) >> 21) & 0xFu) << (4 * (i % 8));
+        }
+    }
+}
+
+// the three per-base fail vectors of an anchored run (--ph window, --qsu, --qsd) in ONE pass over the
+// quality words, so that each word is dead after its use; equal thresholds share the work
+template <int NW, int NQW>
+F2Q_HD void fail_vectors3(const uint32_t (&Q)[NQW], int thr, int thr_up, int thr_down,
+                          uint32_t (&FW)[NW], uint32_t (&FU)[NW], uint32_t (&FD)[NW])
+{
+    const bool su = thr_up == thr, sd = thr_down == thr;             // wave-uniform
+    const uint32_t add_lo = 0x5F5F5F5Fu;
+    const uint32_t hw = thr >= 33 ? (uint32_t)(127 - thr) * 0x01010101u : 0u;
+    const uint32_t hu = thr_up >= 33 ? (uint32_t)(127 - thr_up) * 0x01010101u : 0u;
+    const uint32_t hd = thr_down >= 33 ? (uint32_t)(127 - thr_down) * 0x01010101u : 0u;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { FW[w] = 0; FU[w] = 0; FD[w] = 0; }
+#pragma unroll
+    for (int i = 0; i < NQW; i++) {
+        if (i / 8 < NW) {
+            const int sh = 4 * (i % 8);
+            if (hw) FW[i / 8] |= ((((qfail4(Q[i], add_lo, hw, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << sh;
+            if (!su && hu) FU[i / 8] |= ((((qfail4(Q[i], add_lo, hu, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << sh;
+            if (!sd && hd) FD[i / 8] |= ((((qfail4(Q[i], add_lo, hd, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << sh;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) { if (su) FU[w] = FW[w]; if (sd) FD[w] = FW[w]; }
+}
+
+// result of the extraction stage of one packed read in an anchored run
+struct AnchorWin { int ok; int start, end; };      // ok: 0 = no window (counts as quality-failed, :345-347),
+                                                   //     1 = window [start,end) passed every Phred test, 2 = take the slow routine
+
+// sequence_tinder (:215-285) + the window Phred test (:357) on bit-planes.  FU/FD/FW: fail vectors
+// for --qsu / --qsd / --ph (they may alias when the thresholds coincide).
+template <int NW, int KBU, int KBD>
+F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], int r,
+                               const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW])
+{
+    AnchorWin out; out.ok = 0; out.start = 0; out.end = 0;
+    const int su = run.up_len[0], sd = run.down_len[0];
+    int start, end;
+    if (run.has_up && run.has_down) {
+        uint32_t hu[NW], hd[NW];
+        anchor_hits<NW, KBU>(LO, HI, run.up2, su, run.msu, hu);
+        const int pu = first_hit<NW>(hu, 0, r - su);
+        if (pu < 0) return out;
+        anchor_hits<NW, KBD>(LO, HI, run.down2, sd, run.msd, hd);
+        const int pd = first_hit<NW>(hd, pu + su, r - sd);
+        if (pd < 0) return out;
+        if (any_in_range<NW>(FU, pu, pu + su) || any_in_range<NW>(FD, pd, pd + sd)) return out;
+        start = pu + su; end = pd;
+    } else if (run.has_up) {
+        uint32_t hu[NW];
+        anchor_hits<NW, KBU>(LO, HI, run.up2, su, run.msu, hu);
+        const int pu = first_hit<NW>(hu, 0, r - su);
+        if (pu < 0) return out;
+        if (any_in_range<NW>(FU, pu, pu + su)) return out;
+        start = pu + su; end = start + run.length;
+        if (run.length < 0) { out.ok = 2; return out; }
+        if (end > r) end = r;                                   // Python slice clipping (:354)
+    } else {
+        uint32_t hd[NW];
+        anchor_hits<NW, KBD>(LO, HI, run.down2, sd, run.msd, hd);
+        const int pd = first_hit<NW>(hd, 0, r - sd);
+        if (pd < 0) return out;
+        if (any_in_range<NW>(FD, pd, pd + sd)) return out;
+        start = pd - run.length; end = pd;
+        if (start < 0 || run.length < 0) { out.ok = 2; return out; }   // negative-index slice: rare, slow routine
+    }
+    if (any_in_range<NW>(FW, start, end)) return out;           // window Phred test (:357)
+    out.ok = 1; out.start = start; out.end = end;
+    return out;
+}
+
+// 2-bit interleaved key of window [start, start+L) (L <= 31) from the planes
+template <int NW>
+F2Q_HD uint64_t plane_key(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], int start, int L)
+{
+    return spread32(plane_extract<NW>(LO, start, L)) | (spread32(plane_extract<NW>(HI, start, L)) << 1);
 }
 
 } // namespace f2q

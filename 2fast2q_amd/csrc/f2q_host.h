@@ -192,7 +192,10 @@ struct PackPlan {
     int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
     int from = 0;                  // ... and only [from, need) is ever looked at
     bool inband_n = false;         // non-ACGT window symbols travel as flag bits (all-ACGT library only)
+    bool fast_anchor = false;      // one --us/--ds pair with ACGT anchors: packed bit-plane path
+    int kb = 1;                    // counter bits of the anchor search (1: k <= 1, 3: k <= 7)
 };
+#define F2Q_ANCHOR_MAXLEN 160      // longest read the packed anchored kernel holds in registers (5 x 32 bases)
 
 inline PackPlan make_plan(const RunDev &run)
 {
@@ -201,6 +204,9 @@ inline PackPlan make_plan(const RunDev &run)
                     run.length <= F2Q_REG_MAXLEN && run.start[0] + run.length <= F2Q_PACK_MAXLEN;
     pl.need = pl.fast_fixed ? run.start[0] + run.length : 0;
     pl.from = pl.fast_fixed ? run.start[0] : 0;
+    pl.fast_anchor = !run.fixed && run.n_iter == 1 && run.anchors_packed && run.msu >= 0 && run.msd >= 0 &&
+                     run.msu <= 7 && run.msd <= 7 && run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN;
+    pl.kb = (run.msu <= 1 && run.msd <= 1) ? 1 : 3;
     return pl;
 }
 
@@ -209,6 +215,13 @@ inline PackPlan make_plan(const RunDev &run)
 // relies on 7-bit bytes); such reads take the general path, which works on the raw bytes.
 inline bool read_is_clean(const PackPlan &pl, const Rec &r)
 {
+    if (pl.fast_anchor) {
+        // the anchor search is case-sensitive on the raw read (:337), so only upper-case ACGT reads are packed
+        if (r.qlen != r.len || r.len > F2Q_ANCHOR_MAXLEN) return false;
+        for (uint32_t j = 0; j < r.len; j++)
+            if (base_code(r.seq[j]) > 3u || (r.qual[j] & 0x80)) return false;
+        return true;
+    }
     if (!pl.fast_fixed) return false;
     if (r.qlen != r.len) return false;
     uint32_t b = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
@@ -221,9 +234,11 @@ inline bool read_is_clean(const PackPlan &pl, const Rec &r)
 
 struct HostPacked {
     uint32_t n_tiles = 0, wb = 0, wq = 0, rmax = 0;
+    uint32_t planar_nw = 0;                    // anchored runs: bases stored as bit-planes of this many 32-base words
     uint64_t n_clean = 0;
     std::vector<uint32_t> bases, qual;
     std::vector<uint16_t> len;
+    std::vector<uint32_t> c_index;             // per packed slot: position of the read inside the block
     // general-path records (raw bytes)
     std::vector<uint8_t> raw;                  // seq bytes then qual bytes per record
     std::vector<unsigned long long> g_off;     // per record: offset of seq in raw (qual follows at +len)
@@ -239,7 +254,7 @@ inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostP
         const Rec &r = recs[i];
         if (read_is_clean(pl, r)) {
             clean.push_back(i);
-            uint32_t l = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
+            uint32_t l = pl.fast_anchor ? r.len : (r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need);
             if (l > rmax) rmax = l;
         } else {
             hp.g_off.push_back(hp.raw.size());
@@ -251,7 +266,39 @@ inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostP
     hp.raw.resize(hp.raw.size() + 8, 0);
     hp.n_clean = clean.size();
     if (clean.empty()) return;
+    hp.c_index.assign(((clean.size() + F2Q_TILE - 1) / F2Q_TILE) * F2Q_TILE, 0);
+    for (size_t s = 0; s < clean.size(); s++) hp.c_index[s] = clean[s];
     if (rmax == 0) rmax = 1;
+    if (pl.fast_anchor) {
+        // planar layout; the kernel is instantiated for 3 or 5 words per plane
+        const uint32_t nw = rmax <= 96 ? 3u : 5u;
+        hp.planar_nw = nw; hp.rmax = rmax; hp.wb = 2 * nw; hp.wq = 8 * nw;
+        hp.n_tiles = (uint32_t)((clean.size() + F2Q_TILE - 1) / F2Q_TILE);
+        hp.bases.assign((size_t)hp.n_tiles * hp.wb * F2Q_TILE, 0);
+        hp.qual.assign((size_t)hp.n_tiles * hp.wq * F2Q_TILE, 0);
+        hp.len.assign((size_t)hp.n_tiles * F2Q_TILE, (uint16_t)F2Q_LEN_SKIP);
+        for (size_t s = 0; s < clean.size(); s++) {
+            const Rec &r = recs[clean[s]];
+            const size_t tile = s / F2Q_TILE, lane = s % F2Q_TILE;
+            hp.len[tile * F2Q_TILE + lane] = (uint16_t)r.len;
+            uint32_t *bp = hp.bases.data() + tile * hp.wb * F2Q_TILE + lane;
+            uint32_t *qp = hp.qual.data() + tile * hp.wq * F2Q_TILE + lane;
+            for (uint32_t w = 0; w * 32 < r.len; w++) {
+                uint32_t lo = 0, hi = 0;
+                for (uint32_t j = 0; j < 32 && w * 32 + j < r.len; j++) {
+                    uint32_t c = base_code(r.seq[w * 32 + j]);
+                    lo |= (c & 1u) << j; hi |= ((c >> 1) & 1u) << j;
+                }
+                bp[(size_t)w * F2Q_TILE] = lo; bp[(size_t)(nw + w) * F2Q_TILE] = hi;
+            }
+            for (uint32_t w = 0; w * 4 < r.len; w++) {
+                uint32_t v = 0;
+                for (uint32_t j = 0; j < 4 && w * 4 + j < r.len; j++) v |= (uint32_t)r.qual[w * 4 + j] << (8 * j);
+                qp[(size_t)w * F2Q_TILE] = v;
+            }
+        }
+        return;
+    }
     hp.rmax = rmax; hp.wb = (rmax + 15) / 16; hp.wq = (rmax + 3) / 4;
     hp.n_tiles = (uint32_t)((clean.size() + F2Q_TILE - 1) / F2Q_TILE);
     hp.bases.assign((size_t)hp.n_tiles * hp.wb * F2Q_TILE, 0);
@@ -329,6 +376,19 @@ inline int fill_run(const f2q_params &p, RunDev &r, std::string &err)
             if (l > F2Q_ANCHOR_MAX) { err = "search sequence longer than 128"; return F2Q_EUNSUPPORTED; }
             (side ? r.down_len : r.up_len)[i] = (int)l;
             for (size_t k = 0; k < l; k++) (side ? r.down : r.up)[i][k] = up8((uint8_t)s[k]);      // :547,:550
+        }
+    }
+    // one pair of ACGT-only anchors of 1..32 symbols: eligible for the packed bit-plane search
+    r.anchors_packed = (r.n_iter == 1);
+    for (int side = 0; side < 2 && r.anchors_packed; side++) {
+        const int has = side ? r.has_down : r.has_up;
+        if (!has) continue;
+        const int l = side ? r.down_len[0] : r.up_len[0];
+        if (l < 1 || l > 32) { r.anchors_packed = 0; break; }
+        for (int k = 0; k < l; k++) {
+            uint32_t c = base_code(side ? r.down[0][k] : r.up[0][k]);
+            if (c > 3u) { r.anchors_packed = 0; break; }
+            (side ? r.down2 : r.up2)[k] = (uint8_t)c;
         }
     }
     return F2Q_OK;

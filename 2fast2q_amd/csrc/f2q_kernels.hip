@@ -294,6 +294,143 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     }
 }
 
+// ---- fast path, anchored ------------------------------------------------------------------------------
+// One lane = one read of a planar tile (bit-planes, see f2q_device.h).  Every byte of every read is
+// needed here (the anchors can sit anywhere, the Phred tests follow them), so this is the kernel that
+// streams the full 188 B/read: 2*NW base words + 8*NW quality words + the length per lane, all as
+// coalesced 256-byte rows.  Counter mode: exact probe, misses queued per wave for the pigeonhole
+// search, LDS histogram.  Extract+Count mode: single-word insert into the device table.
+#define F2Q_AN_THREADS 256
+#define F2Q_AN_WAVES (F2Q_AN_THREADS / 64)
+
+// odd geometry (negative-index slices, windows the 2-bit tables cannot hold): the byte-exact general routine
+// on a private copy of the read, rebuilt from the tile in memory so that the caller keeps nothing live for it
+__device__ __noinline__ void anchor_slow(const RunDev *run, const LibDev *lib, const EcDev *ec, const Accum *acc,
+                                         const PackedBlock *pb, uint32_t tile, uint32_t slot, int r,
+                                         unsigned long long read_index, unsigned long long *st)
+{
+    uint8_t seq[F2Q_ANCHOR_MAXLEN], qual[F2Q_ANCHOR_MAXLEN];
+    const uint32_t nw = pb->planar_nw;
+    const auto bp = gp(pb->bases) + (uint64_t)tile * pb->wb * F2Q_TILE + slot;
+    const auto qp = gp(pb->qual) + (uint64_t)tile * pb->wq * F2Q_TILE + slot;
+    if (r > F2Q_ANCHOR_MAXLEN) r = F2Q_ANCHOR_MAXLEN;
+    for (int i = 0; i < r; i++) {
+        const uint32_t lo = bp[(uint64_t)(i >> 5) * F2Q_TILE], hi = bp[(uint64_t)(nw + (i >> 5)) * F2Q_TILE];
+        seq[i] = (uint8_t)"ACGT"[((lo >> (i & 31)) & 1u) | (((hi >> (i & 31)) & 1u) << 1)];
+        qual[i] = (uint8_t)((qp[(uint64_t)(i >> 2) * F2Q_TILE] >> (8 * (i & 3))) & 0xFFu);
+    }
+    general_read<const uint8_t *>(*run, *lib, *ec, *acc, seq, r, qual, r, read_index, st);
+}
+
+template <int NW, int KB, bool EC, bool USE_LDS>
+__global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *__restrict__ runp,
+                                                                  const LibDev *__restrict__ libp, EcDev ec,
+                                                                  PackedBlock pb, Accum acc, uint64_t read_base)
+{
+    constexpr int NQW = 8 * NW;
+    extern __shared__ unsigned long long smem64[];
+    unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_V2_QCAP);
+    __shared__ uint32_t q_tails[F2Q_AN_WAVES];
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (USE_LDS && !EC) for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) hist[i] = 0;
+    if (tid < F2Q_AN_WAVES) q_tails[tid] = 0;
+    __syncthreads();
+    uint32_t *q_tail = &q_tails[wave];
+    uint32_t q_head = 0;
+    const bool do_near = run.miss > 0;
+    const int pk_len = (int)lib.pk.len;
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+
+    auto count_hit = [&](uint32_t idx) {
+        if (USE_LDS) atomicAdd(&hist[idx], 1u);
+        else acc_add(&acc.counts[idx], 1ull);
+    };
+
+    for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
+        const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + tid;
+        const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + tid;
+        uint32_t LO[NW], HI[NW], Q[NQW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            LO[w] = __builtin_nontemporal_load(bp + (uint64_t)w * F2Q_TILE);
+            HI[w] = __builtin_nontemporal_load(bp + (uint64_t)(NW + w) * F2Q_TILE);
+        }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) {
+            const uint32_t row = (uint32_t)i < pb.wq ? (uint32_t)i : pb.wq - 1u;
+            Q[i] = __builtin_nontemporal_load(qp + (uint64_t)row * F2Q_TILE);
+        }
+        const uint32_t l = pb.len ? gp(pb.len)[(uint64_t)tile * F2Q_TILE + tid] : pb.rmax;
+        if (l != F2Q_LEN_SKIP) {
+            const int r = (int)l;
+            const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
+            const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+            uint32_t FW[NW], FU[NW], FD[NW];
+            fail_vectors3<NW, NQW>(Q, run.thr, run.thr_up, run.thr_down, FW, FU, FD);
+            const AnchorWin aw = anchor_window<NW, KB, KB>(run, LO, HI, r, FU, FD, FW);
+            const int L = aw.end - aw.start;
+            if (aw.ok == 0) { st[4]++; st[0]++; }
+            else if (aw.ok == 2 || L < 1 || L > (EC ? F2Q_EC64_MAXLEN : F2Q_REG_MAXLEN)) {
+                unsigned long long st2[5] = {0, 0, 0, 0, 0};
+                const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
+                anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st2);
+#pragma unroll
+                for (int k = 0; k < 5; k++) st[k] += st2[k];
+            } else {
+                const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
+                st[0]++;
+                if (EC) { ec64_insert(ec, key, L, gi); st[1]++; }
+                else if (L == pk_len) {
+                    const int e = packed_exact(lib, key);
+                    if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
+                    else if (!do_near) st[3]++;
+                    else { uint32_t at = atomicAdd(q_tail, 1u); queue[at % F2Q_V2_QCAP] = key; }
+                } else {
+                    // a window of another length than the packed tables index: wide tables, in place (rare)
+                    const int e = lib_exact(lib, key, L);
+                    if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
+                    else {
+                        MinTrack t; t.init(run.miss);
+                        if (do_near) lib_near(lib, key, L, 0ull, t);
+                        if (t.cnt == 1) { count_hit(t.idx); st[2]++; } else st[3]++;
+                    }
+                }
+            }
+        }
+        if (!EC && do_near) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+            while (tail - q_head >= 64u) {
+                uint32_t idx = 0;
+                int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], 0u, &idx);
+                if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
+                q_head += 64u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    if (!EC && do_near) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+        if (lane < tail - q_head) {
+            uint32_t idx = 0;
+            int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], 0u, &idx);
+            if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
+        }
+    }
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
+    if (USE_LDS && !EC) {
+        __syncthreads();
+        auto row = gpw(acc.slab) + (uint64_t)blockIdx.x * nf;
+        for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) row[i] = hist[i];
+    }
+}
+
 // counts[f] += sum over workgroups of slab[w][f].  Block = 64 features x 4 row lanes; grid.y splits
 // the rows further so that every thread has ~16 independent loads in flight.
 #define F2Q_RED_SPLIT 8u
@@ -385,10 +522,27 @@ __global__ void k_ec_rehash(EcDev old, unsigned long long n_old, EcDev nw)
     }
 }
 
+// move every key of the old single-word table into the new one (keys are distinct)
+__global__ void k_ec64_rehash(EcDev old, EcDev nw)
+{
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > old.k64_mask) return;
+    const unsigned long long k = old.k64_slots[i];
+    if (k == KEY_EMPTY) return;
+    uint32_t s = hash32(k ^ (k >> 29), 32) & nw.k64_mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&nw.k64_slots[s], KEY_EMPTY, k);
+        if (prev == KEY_EMPTY) break;
+        s = (s + 1) & nw.k64_mask;
+    }
+    nw.k64_count[s] = old.k64_count[i]; nw.k64_first[s] = old.k64_first[i];
+    atomicAdd(&nw.ctr[3], 1ull);
+}
+
 // ---- synthetic workload, device side ----------------------------------------------------------
 struct SynthOut {
     // packed planes (may be null when everything goes to the general path)
-    uint32_t *bases, *qual; uint16_t *len; uint32_t wb, wq;
+    uint32_t *bases, *qual; uint16_t *len; uint32_t wb, wq, planar_nw;
     // general records: fixed stride R for seq and R for quality
     uint8_t *raw; unsigned long long *off; uint32_t *glen, *gqlen, *gindex;
     unsigned long long *g_count; unsigned long long g_cap;
@@ -430,15 +584,23 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
     uint32_t *bp = o.bases + (tile * o.wb) * F2Q_TILE + lane;
     uint32_t *qp = o.qual + (tile * o.wq) * F2Q_TILE + lane;
     uint64_t fw = 0;
-    uint32_t bw = 0, qw = 0;
+    uint32_t bw = 0, qw = 0, lw = 0, hw = 0;
     for (int p = 0; p < R; p++) {
         if ((p & 31) == 0) fw = rnd(s.seed, i, F_FLANK0 + (p >> 5));
         uint8_t c = synth_base(s, r, p, fw);
         uint32_t code = base_code(c); if (code > 3u) code = 0;
-        bw |= code << (2 * (p & 15));
-        qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * (p & 3));
-        if ((p & 15) == 15 || p == R - 1) { bp[(uint64_t)(p >> 4) * F2Q_TILE] = bw; bw = 0; }
+        qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | ((p == npos && !o.planar_nw) ? 0x80u : 0u)) << (8 * (p & 3));
         if ((p & 3) == 3 || p == R - 1) { qp[(uint64_t)(p >> 2) * F2Q_TILE] = qw; qw = 0; }
+        if (o.planar_nw) {                       // anchored runs: bit-planes, 32 bases per word
+            lw |= (code & 1u) << (p & 31); hw |= (code >> 1) << (p & 31);
+            if ((p & 31) == 31 || p == R - 1) {
+                bp[(uint64_t)(p >> 5) * F2Q_TILE] = lw; bp[(uint64_t)(o.planar_nw + (p >> 5)) * F2Q_TILE] = hw;
+                lw = 0; hw = 0;
+            }
+        } else {
+            bw |= code << (2 * (p & 15));
+            if ((p & 15) == 15 || p == R - 1) { bp[(uint64_t)(p >> 4) * F2Q_TILE] = bw; bw = 0; }
+        }
     }
 }
 
@@ -472,6 +634,9 @@ struct f2q_ctx {
     LibDev *lib_d = nullptr;
     std::vector<void *> lib_allocs;
     uint64_t *guide_keys_d = nullptr;
+    std::vector<uint64_t> synth_keys;    // generator guides set by f2q_synth_guides (else the library's)
+    uint64_t *synth_keys_d = nullptr;
+    uint32_t synth_glen = 0;
     // accumulators: counts[n_features] then stats[5]
     unsigned long long *acc_d = nullptr;
     uint64_t acc_n = 0;
@@ -642,6 +807,7 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_all(c->lib_allocs); free_all(c->ec_allocs);
     if (c->acc_d) (void)hipFree(c->acc_d);
+    if (c->synth_keys_d) (void)hipFree(c->synth_keys_d);
     if (c->slab_d) (void)hipFree(c->slab_d);
     if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
     if (c->run_d) (void)hipFree(c->run_d);
@@ -659,12 +825,21 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     if (c->prm.mode != 0) return fail(c, F2Q_ESTATE, "Extract+Count mode takes no feature library (fast2q.py:1701)");
     HIPC(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < n; i++) if (offs[i + 1] < offs[i]) return fail(c, F2Q_EINVAL, "offsets must be non-decreasing");
-    build_index(c->ix, seqs ? seqs : "", offs, n, c->run_h.miss, c->plan.fast_fixed ? c->run_h.length : 0);
+    int packed_len = c->plan.fast_fixed ? c->run_h.length : 0;
+    if (c->plan.fast_anchor) {
+        if (c->run_h.has_up && c->run_h.has_down) {          // variable windows: index the most common feature length
+            std::vector<uint32_t> hist(F2Q_REG_MAXLEN + 1, 0);
+            for (uint32_t i = 0; i < n; i++) { uint32_t l = offs[i + 1] - offs[i]; if (l >= 1 && l <= F2Q_REG_MAXLEN) hist[l]++; }
+            packed_len = (int)(std::max_element(hist.begin(), hist.end()) - hist.begin());
+        } else packed_len = c->run_h.length;
+    }
+    build_index(c->ix, seqs ? seqs : "", offs, n, c->run_h.miss, packed_len);
     int rc = upload_lib(c);
     if (rc) return rc;
     rc = alloc_acc(c, n);
     if (rc) return rc;
     c->plan.inband_n = c->plan.fast_fixed && c->ix.n_irregular == 0;
+    if (c->ix.n_irregular) c->plan.fast_anchor = false;      // irregular features need the byte-exact routine
     c->have_lib = true;
     return F2Q_OK;
 }
@@ -721,6 +896,10 @@ static int ec_alloc(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t m
     if ((rc = dev_alloc(c, max_entries, &e.ent_first, owner, 0xFF))) return rc;
     if ((rc = dev_alloc(c, arena_words, &e.arena, owner))) return rc;
     if ((rc = dev_alloc(c, (size_t)4, &e.ctr, owner, 0))) return rc;
+    if ((rc = dev_alloc(c, slots, &e.k64_slots, owner, 0xFF))) return rc;
+    if ((rc = dev_alloc(c, slots, &e.k64_count, owner, 0))) return rc;
+    if ((rc = dev_alloc(c, slots, &e.k64_first, owner, 0xFF))) return rc;
+    e.k64_mask = (uint32_t)(slots - 1);
     e.mask = (uint32_t)(slots - 1); e.max_entries = (uint32_t)std::min<uint64_t>(max_entries, 0xFFFFFFFEull);
     e.arena_words = arena_words;
     return F2Q_OK;
@@ -734,7 +913,8 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
         HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
-    const uint64_t need_e = ctr[0] + reads + 16, need_w = ctr[1] + (key_bytes + 3) / 4 + reads + 16;
+    // both tables are sized for "every read brings a new key": slots = 2 * max_entries
+    const uint64_t need_e = std::max(ctr[0], ctr[3]) + reads + 16, need_w = ctr[1] + (key_bytes + 3) / 4 + reads + 16;
     if (c->ec.slots && need_e <= c->ec.max_entries && need_w <= c->ec.arena_words) return F2Q_OK;
     uint64_t ne = std::max<uint64_t>(need_e * 2, 1u << 16), nw = std::max<uint64_t>(need_w * 2, 1u << 18);
     EcDev fresh; std::vector<void *> owner;
@@ -743,8 +923,12 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
     if (c->ec.slots && ctr[0]) {
         hipLaunchKernelGGL(k_ec_rehash, dim3((unsigned)((ctr[0] + 255) / 256)), dim3(256), 0, c->stream, c->ec, ctr[0], fresh);
         HIPC(c, hipGetLastError());
-        HIPC(c, hipStreamSynchronize(c->stream));
     }
+    if (c->ec.slots && ctr[3]) {
+        hipLaunchKernelGGL(k_ec64_rehash, dim3((unsigned)(((uint64_t)c->ec.k64_mask + 256) / 256)), dim3(256), 0, c->stream, c->ec, fresh);
+        HIPC(c, hipGetLastError());
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
     free_all(c->ec_allocs);
     c->ec_allocs = owner; c->ec = fresh;
     return F2Q_OK;
@@ -755,15 +939,56 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
 {
     if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
     Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr};
-    if (c->prm.mode == 1 && b->rb.n) {
+    if (c->prm.mode == 1 && b->n_reads) {
         // worst case every read inserts a new key made of all its windows
         uint64_t key_bytes = b->dev_bytes;   // upper bound: no key is longer than the read's bytes + separators
-        int rc = ec_reserve(c, b->rb.n, key_bytes + (uint64_t)b->rb.n * F2Q_MAX_ITER);
+        int rc = ec_reserve(c, b->n_reads, key_bytes + (uint64_t)b->n_reads * F2Q_MAX_ITER);
         if (rc) return rc;
     }
     uint32_t launches = 0;
     HIPC(c, hipEventRecord(c->ev_k0, c->stream));
-    if (b->pb.n_tiles) {
+    if (b->pb.n_tiles && b->pb.planar_nw) {
+        // packed anchored path
+        const bool ecm = c->prm.mode == 1;
+        const bool lds = !ecm && c->lib_h.n_features <= F2Q_HIST_MAX;
+        const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * 4u);
+        const size_t shmem = (size_t)F2Q_AN_WAVES * F2Q_V2_QCAP * 8 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
+        if (!ecm) {
+            const size_t need = lds ? (size_t)grid * c->lib_h.n_features : 0;
+            if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
+                if (c->slab_d) (void)hipFree(c->slab_d);
+                if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
+                c->slab_d = nullptr; c->slab_n = 0; c->stat_slab_d = nullptr; c->stat_slab_n = 0;
+                HIPC(c, hipMalloc((void **)&c->slab_d, std::max<size_t>(need, 1) * sizeof(uint32_t)));
+                HIPC(c, hipMalloc((void **)&c->stat_slab_d, (size_t)grid * 8 * sizeof(unsigned long long)));
+                c->slab_n = need; c->stat_slab_n = grid;
+            }
+            if (lds) { acc.slab = c->slab_d; acc.stat_slab = c->stat_slab_d; }
+        }
+        const int nw = (int)b->pb.planar_nw, kb = c->plan.kb;
+#define F2Q_LAUNCH_AN(NW_, KB_)                                                                                      \
+        do {                                                                                                         \
+            if (ecm) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, true, false>), dim3(grid), dim3(F2Q_AN_THREADS), shmem, \
+                                        c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);            \
+            else if (lds) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, true>), dim3(grid), dim3(F2Q_AN_THREADS),   \
+                                             shmem, c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen); \
+            else hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, false>), dim3(grid), dim3(F2Q_AN_THREADS), shmem,    \
+                                    c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);                \
+        } while (0)
+        if (nw == 3 && kb == 1) F2Q_LAUNCH_AN(3, 1);
+        else if (nw == 3) F2Q_LAUNCH_AN(3, 3);
+        else if (kb == 1) F2Q_LAUNCH_AN(5, 1);
+        else F2Q_LAUNCH_AN(5, 3);
+#undef F2Q_LAUNCH_AN
+        HIPC(c, hipGetLastError());
+        launches++;
+        if (lds && c->lib_h.n_features) {
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((c->lib_h.n_features + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
+                               c->slab_d, grid, c->lib_h.n_features, acc.counts, c->stat_slab_d, acc.stats);
+            HIPC(c, hipGetLastError());
+            launches++;
+        }
+    } else if (b->pb.n_tiles) {
         const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
         const bool v2 = !c->force_v1 && c->lib_h.pk.len == (uint32_t)c->run_h.length && c->lib_h.pk.len > 0 &&
                         c->lib_h.n_irregular == 0;
@@ -825,7 +1050,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
         t->fast_reads = b->n_reads - b->n_general; t->launches = launches;
     }
-    if (c->prm.mode == 1 && b->rb.n) {
+    if (c->prm.mode == 1 && b->n_reads) {
         unsigned long long ctr[4];
         HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -880,8 +1105,11 @@ static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_bloc
             if ((rc = dev_upload(c, hp.bases.data(), hp.bases.size(), &db, b->allocs))) break;
             if ((rc = dev_upload(c, hp.qual.data(), hp.qual.size(), &dq, b->allocs))) break;
             if ((rc = dev_upload(c, hp.len.data(), hp.len.size(), &dl, b->allocs))) break;
+            uint32_t *dci = nullptr;
+            if (c->prm.mode == 1 && (rc = dev_upload(c, hp.c_index.data(), hp.c_index.size(), &dci, b->allocs))) break;
+            b->pb.index = dci;
             b->pb.n_slots = (uint64_t)hp.n_tiles * F2Q_TILE; b->pb.n_tiles = hp.n_tiles;
-            b->pb.wb = hp.wb; b->pb.wq = hp.wq; b->pb.rmax = hp.rmax;
+            b->pb.wb = hp.wb; b->pb.wq = hp.wq; b->pb.rmax = hp.rmax; b->pb.planar_nw = hp.planar_nw;
             b->pb.bases = db; b->pb.qual = dq; b->pb.len = dl;
             b->dev_bytes += hp.bases.size() * 4 + hp.qual.size() * 4 + hp.len.size() * 2;
         }
@@ -985,19 +1213,38 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
 }
 
 // ---- synthetic workload ---------------------------------------------------------------------------
+extern "C" int f2q_synth_guides(f2q_ctx *c, const char *seqs, uint32_t n, uint32_t length)
+{
+    if (!c || !seqs || n == 0 || length < 1 || length > F2Q_REG_MAXLEN) return fail(c, F2Q_EINVAL, "f2q_synth_guides: bad argument");
+    HIPC(c, hipSetDevice(c->device));
+    std::vector<uint64_t> keys(n);
+    for (uint32_t g = 0; g < n; g++)
+        if (!feature_key((const uint8_t *)seqs + (size_t)g * length, length, keys[g])) return fail(c, F2Q_EINVAL, "synthetic guides must be ACGT");
+    if (c->synth_keys_d) { (void)hipFree(c->synth_keys_d); c->synth_keys_d = nullptr; }
+    HIPC(c, hipMalloc((void **)&c->synth_keys_d, (size_t)n * 8));
+    HIPC(c, hipMemcpy(c->synth_keys_d, keys.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    c->synth_keys.swap(keys); c->synth_glen = length;
+    return F2Q_OK;
+}
+
 static int synth_to_dev(f2q_ctx *c, const f2q_synth *s, SynthDev &d)
 {
     memset(&d, 0, sizeof d);
-    if (!c->have_lib || c->ix.n_features == 0) return fail(c, F2Q_ESTATE, "synthetic reads need a feature library (f2q_set_features)");
-    uint32_t glen = c->ix.feat_off[1] - c->ix.feat_off[0];
-    for (uint32_t f = 0; f < c->ix.n_features; f++) {
-        uint64_t k;
-        if (c->ix.feat_off[f + 1] - c->ix.feat_off[f] != glen || !feature_key(c->ix.feat_bytes.data() + c->ix.feat_off[f], glen, k))
-            return fail(c, F2Q_EUNSUPPORTED, "synthetic reads need a uniform-length ACGT library (<= 31 bp)");
+    uint32_t glen;
+    if (!c->synth_keys.empty()) { glen = c->synth_glen; d.n_guides = (int)c->synth_keys.size(); }
+    else {
+        if (!c->have_lib || c->ix.n_features == 0) return fail(c, F2Q_ESTATE, "synthetic reads need guides (f2q_set_features or f2q_synth_guides)");
+        glen = c->ix.feat_off[1] - c->ix.feat_off[0];
+        for (uint32_t f = 0; f < c->ix.n_features; f++) {
+            uint64_t k;
+            if (c->ix.feat_off[f + 1] - c->ix.feat_off[f] != glen || !feature_key(c->ix.feat_bytes.data() + c->ix.feat_off[f], glen, k))
+                return fail(c, F2Q_EUNSUPPORTED, "synthetic reads need a uniform-length ACGT library (<= 31 bp)");
+        }
+        d.n_guides = (int)c->ix.n_features;
     }
     d.seed = s->seed; d.n_reads = s->n_reads; d.first_read = s->first_read;
     d.read_len = s->read_len; d.start = s->start; d.cassette = s->cassette; d.max_offset = s->max_offset;
-    d.glen = (int)glen; d.n_guides = (int)c->ix.n_features;
+    d.glen = (int)glen;
     d.t_sub = s->t_sub; d.t_rand = s->t_rand; d.t_n = s->t_n; d.t_lowq = s->t_lowq; d.t_q29 = s->t_q29; d.t_q28 = s->t_q28;
     if (s->read_len < 1 || s->read_len > F2Q_PACK_MAXLEN) return fail(c, F2Q_EINVAL, "read_len must be 1..512");
     if (s->cassette) {
@@ -1050,7 +1297,7 @@ extern "C" int f2q_synth_fastq(f2q_ctx *c, const f2q_synth *s, uint64_t lo, uint
     if (!buf) { *nbytes = need; return F2Q_OK; }
     if (*nbytes < need) { *nbytes = need; return fail(c, F2Q_EINVAL, "buffer too small"); }
     size_t o = 0;
-    const uint64_t *keys = c->ix.key2.data();
+    const uint64_t *keys = c->synth_keys.empty() ? c->ix.key2.data() : c->synth_keys.data();
     for (uint64_t i = lo; i < hi; i++) {
         SynthRead r = synth_plan(d, i, [&](uint32_t g) { return keys[g]; });
         o += (size_t)snprintf((char *)buf + o, 32, "@r%llu\n", (unsigned long long)i);
@@ -1078,10 +1325,12 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
     const int R = d.read_len;
     f2q_block *b = new f2q_block();
     b->n_reads = s->n_reads;
-    const bool fast = c->plan.fast_fixed;
+    const bool planar = c->plan.fast_anchor && R <= F2Q_ANCHOR_MAXLEN;
+    const bool fast = c->plan.fast_fixed || planar;
     SynthOut o; memset(&o, 0, sizeof o);
     o.all_general = fast ? 0 : 1;
-    o.inband_n = c->plan.inband_n ? 1 : 0;
+    o.inband_n = (c->plan.inband_n && !planar) ? 1 : 0;
+    o.planar_nw = planar ? (R <= 96 ? 3u : 5u) : 0u;
     const uint64_t n_tiles = (s->n_reads + F2Q_TILE - 1) / F2Q_TILE;
     const uint64_t n_slots = n_tiles * F2Q_TILE;
     // general-path capacity: everything, or the expected 'N' share with a wide margin
@@ -1091,7 +1340,8 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
     if (gcap == 0) gcap = 1;
     do {
         if (fast) {
-            o.wb = (uint32_t)((R + 15) / 16); o.wq = (uint32_t)((R + 3) / 4);
+            o.wb = planar ? 2 * o.planar_nw : (uint32_t)((R + 15) / 16);
+            o.wq = planar ? 8 * o.planar_nw : (uint32_t)((R + 3) / 4);
             if ((rc = dev_alloc(c, (size_t)n_tiles * o.wb * F2Q_TILE, &o.bases, b->allocs, 0))) break;
             if ((rc = dev_alloc(c, (size_t)n_tiles * o.wq * F2Q_TILE, &o.qual, b->allocs, 0))) break;
             if ((rc = dev_alloc(c, (size_t)n_slots, &o.len, b->allocs))) break;
@@ -1104,7 +1354,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
         if ((rc = dev_alloc(c, (size_t)gcap, &o.gindex, b->allocs))) break;
         if ((rc = dev_alloc(c, (size_t)1, &o.g_count, b->allocs, 0))) break;
         o.g_cap = gcap;
-        hipLaunchKernelGGL(k_synth, dim3((unsigned)n_tiles), dim3(F2Q_TILE), 0, c->stream, d, c->guide_keys_d, o, n_slots);
+        hipLaunchKernelGGL(k_synth, dim3((unsigned)n_tiles), dim3(F2Q_TILE), 0, c->stream, d, c->synth_keys.empty() ? c->guide_keys_d : c->synth_keys_d, o, n_slots);
         hipError_t e = hipGetLastError();
         unsigned long long g = 0;
         if (e == hipSuccess) e = hipMemcpyAsync(&g, o.g_count, sizeof g, hipMemcpyDeviceToHost, c->stream);
@@ -1114,6 +1364,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
         b->n_general = g;
         if (fast) {
             b->pb.n_slots = n_slots; b->pb.n_tiles = (uint32_t)n_tiles; b->pb.wb = o.wb; b->pb.wq = o.wq; b->pb.rmax = (uint32_t)R;
+            b->pb.planar_nw = o.planar_nw;
             b->pb.bases = o.bases; b->pb.qual = o.qual; b->pb.len = o.len;
         }
         b->rb.n = g; b->rb.raw = o.raw; b->rb.off = o.off; b->rb.len = o.glen; b->rb.qlen = o.gqlen; b->rb.index = o.gindex;
@@ -1126,20 +1377,59 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
 }
 
 // ---- Extract+Count results ----------------------------------------------------------------------
+// both Extract+Count tables, pulled to the host: the byte-string entries then the occupied single-word slots
+struct EcHost {
+    std::vector<std::string> keys;
+    std::vector<unsigned long long> cnt, first;
+};
+static int ec_pull(f2q_ctx *c, EcHost &h)
+{
+    if (!c->ec.slots) return F2Q_OK;
+    unsigned long long ctr[4];
+    HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error)");
+    const uint64_t n = ctr[0];
+    if (n) {
+        std::vector<uint32_t> len(n), arena(ctr[1] ? ctr[1] : 1);
+        std::vector<unsigned long long> off(n), cnt(n), first(n);
+        HIPC(c, hipMemcpy(len.data(), c->ec.ent_len, n * 4, hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(off.data(), c->ec.ent_off, n * 8, hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(cnt.data(), c->ec.ent_count, n * 8, hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(first.data(), c->ec.ent_first, n * 8, hipMemcpyDeviceToHost));
+        if (ctr[1]) HIPC(c, hipMemcpy(arena.data(), c->ec.arena, ctr[1] * 4, hipMemcpyDeviceToHost));
+        for (uint64_t e = 0; e < n; e++) {
+            h.keys.emplace_back((const char *)(arena.data() + off[e]), len[e]);
+            h.cnt.push_back(cnt[e]); h.first.push_back(first[e]);
+        }
+    }
+    if (ctr[3]) {
+        const size_t ns = (size_t)c->ec.k64_mask + 1;
+        std::vector<unsigned long long> ks(ns), kc(ns), kf(ns);
+        HIPC(c, hipMemcpy(ks.data(), c->ec.k64_slots, ns * 8, hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(kc.data(), c->ec.k64_count, ns * 8, hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(kf.data(), c->ec.k64_first, ns * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ns; i++) {
+            if (ks[i] == KEY_EMPTY) continue;
+            const uint32_t len = (uint32_t)(ks[i] >> 58);
+            std::string k(len, 'A');
+            for (uint32_t j = 0; j < len; j++) k[j] = "ACGT"[(ks[i] >> (2 * j)) & 3];
+            h.keys.push_back(k); h.cnt.push_back(kc[i]); h.first.push_back(kf[i]);
+        }
+    }
+    return F2Q_OK;
+}
+
 extern "C" int f2q_ec_size(f2q_ctx *c, uint64_t *n_keys, uint64_t *n_bytes)
 {
     if (!c || !n_keys || !n_bytes) return F2Q_EINVAL;
     *n_keys = 0; *n_bytes = 0;
     if (c->prm.mode != 1) return fail(c, F2Q_ESTATE, "not in Extract+Count mode");
-    if (!c->ec.slots) return F2Q_OK;
     HIPC(c, hipSetDevice(c->device));
-    unsigned long long ctr[4];
-    HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> len(ctr[0]);
-    if (ctr[0]) HIPC(c, hipMemcpy(len.data(), c->ec.ent_len, ctr[0] * 4, hipMemcpyDeviceToHost));
-    uint64_t nb = 0; for (uint32_t l : len) nb += l;
-    *n_keys = ctr[0]; *n_bytes = nb;
+    EcHost h; int rc = ec_pull(c, h);
+    if (rc) return rc;
+    uint64_t nb = 0; for (auto &k : h.keys) nb += k.size();
+    *n_keys = h.keys.size(); *n_bytes = nb;
     return F2Q_OK;
 }
 
@@ -1148,26 +1438,15 @@ extern "C" int f2q_ec_fetch(f2q_ctx *c, char *keys, uint64_t *offs, int64_t *cou
     if (!c || !offs) return F2Q_EINVAL;
     if (c->prm.mode != 1) return fail(c, F2Q_ESTATE, "not in Extract+Count mode");
     offs[0] = 0;
-    if (!c->ec.slots) return F2Q_OK;
     HIPC(c, hipSetDevice(c->device));
-    unsigned long long ctr[4];
-    HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    const uint64_t n = ctr[0];
-    if (!n) return F2Q_OK;
-    std::vector<uint32_t> len(n), arena(ctr[1] ? ctr[1] : 1);
-    std::vector<unsigned long long> off(n), cnt(n), first(n);
-    HIPC(c, hipMemcpy(len.data(), c->ec.ent_len, n * 4, hipMemcpyDeviceToHost));
-    HIPC(c, hipMemcpy(off.data(), c->ec.ent_off, n * 8, hipMemcpyDeviceToHost));
-    HIPC(c, hipMemcpy(cnt.data(), c->ec.ent_count, n * 8, hipMemcpyDeviceToHost));
-    HIPC(c, hipMemcpy(first.data(), c->ec.ent_first, n * 8, hipMemcpyDeviceToHost));
-    if (ctr[1]) HIPC(c, hipMemcpy(arena.data(), c->ec.arena, ctr[1] * 4, hipMemcpyDeviceToHost));
+    EcHost h; int rc = ec_pull(c, h);
+    if (rc) return rc;
     uint64_t o = 0;
-    for (uint64_t e = 0; e < n; e++) {
-        if (keys) memcpy(keys + o, (const uint8_t *)(arena.data() + off[e]), len[e]);
-        o += len[e]; offs[e + 1] = o;
-        if (counts) counts[e] = (int64_t)cnt[e];
-        if (first_read) first_read[e] = first[e];
+    for (size_t e = 0; e < h.keys.size(); e++) {
+        if (keys) memcpy(keys + o, h.keys[e].data(), h.keys[e].size());
+        o += h.keys[e].size(); offs[e + 1] = o;
+        if (counts) counts[e] = (int64_t)h.cnt[e];
+        if (first_read) first_read[e] = h.first[e];
     }
     return F2Q_OK;
 }

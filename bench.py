@@ -22,7 +22,11 @@ WORKLOADS = {
     "cfg2_10M_1k_m0": dict(n_reads=10_000_000, n_guides=1000, miss=0, lib_seed=0xF2A5 + 2),
     "cfg3_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 3),
     "cfg4_50M_100k_m1": dict(n_reads=50_000_000, n_guides=100000, miss=1, lib_seed=0xF2A5 + 4),
+    # config 5: up+guide+down cassette at a uniform offset in [0,100]; --us/--ds anchored search
+    "cfg5a_50M_10k_anchor_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True),
+    "cfg5b_50M_anchor_ec": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True, ec=True),
 }
+UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
 B_ALG = 188           # algorithmic bytes per 150-bp read: 38 B of 2-bit bases + 150 quality bytes
 HBM_PEAK_GBS = 8000.0
 
@@ -77,9 +81,18 @@ def main():
     if a.miss is not None:
         w["miss"] = a.miss
     guides = pkg.binding.synth_library(w["lib_seed"], w["n_guides"], 20)
-    c = pkg.Counter(features=guides, miss=w["miss"], phred=a.phred, length=20, start="0", device=local)
     n = w["n_reads"]
-    blk = c.synth_create(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=a.read_len, p_n=a.p_n)
+    if w.get("anchored"):
+        # the generator needs the library; an EC context has none, so generate through a Counter context's spec
+        akw = dict(upstream=UP, downstream=DOWN, miss_search_up=1, miss_search_down=1)
+        c = pkg.Counter(features=None if w.get("ec") else guides, mode="EC" if w.get("ec") else "C", miss=w["miss"],
+                        phred=a.phred, device=local, **akw)
+        spec = dict(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=a.read_len, p_n=a.p_n, cassette=True, up=UP,
+                    down=DOWN, max_offset=100)
+        blk = c.synth_create(guides=guides, **spec) if w.get("ec") else c.synth_create(**spec)
+    else:
+        c = pkg.Counter(features=guides, miss=w["miss"], phred=a.phred, length=20, start="0", device=local)
+        blk = c.synth_create(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=a.read_len, p_n=a.p_n)
     info = blk.info()
 
     # the device accumulator as a torch tensor, so RCCL can all-reduce it in place

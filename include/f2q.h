@@ -132,6 +132,9 @@ int f2q_count_resident(f2q_ctx *ctx, const f2q_block *blk, f2q_timing *t);
 int f2q_block_info(const f2q_block *blk, uint64_t *n_reads, uint64_t *n_general, uint64_t *device_bytes);
 void f2q_block_free(f2q_ctx *ctx, f2q_block *blk);
 
+/* The guide set the generator plants into reads: by default the library given to f2q_set_features;
+ * Extract+Count contexts (which take no library) and tests set it explicitly. n*length ACGT bytes. */
+int f2q_synth_guides(f2q_ctx *ctx, const char *seqs, uint32_t n, uint32_t length);
 /* Host-side twin of the device generator: FASTQ text of reads [lo,hi) of `spec` against the
  * library given to f2q_set_features. Two-call pattern: buf == NULL returns the size in *nbytes. */
 int f2q_synth_fastq(f2q_ctx *ctx, const f2q_synth *spec, uint64_t lo, uint64_t hi, uint8_t *buf, size_t *nbytes);

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -19,8 +20,8 @@ using namespace f2q;
 struct Emu {
     RunDev run; PackPlan plan; HostIndex ix; LibDev lib;
     std::vector<unsigned long long> acc;      // counts + 5 stats
-    EcDev ec; std::vector<unsigned long long> slots, ent_off, ent_count, ent_first, ctr; std::vector<uint32_t> ent_len, arena;
-    uint64_t reads_seen = 0, fast = 0, general = 0, v2_reads = 0;
+    EcDev ec; std::vector<unsigned long long> slots, ent_off, ent_count, ent_first, ctr, k64s, k64c, k64f; std::vector<uint32_t> ent_len, arena;
+    uint64_t reads_seen = 0, fast = 0, general = 0, v2_reads = 0, anchor_reads = 0;
     int use_v2 = 1;
     std::string err;
 };
@@ -52,6 +53,8 @@ void *emu_create(const f2q_params *p)
     e->ec.slots = e->slots.data(); e->ec.mask = slots - 1; e->ec.max_entries = cap; e->ec.ent_off = e->ent_off.data();
     e->ec.ent_len = e->ent_len.data(); e->ec.ent_count = e->ent_count.data(); e->ec.ent_first = e->ent_first.data();
     e->ec.arena = e->arena.data(); e->ec.arena_words = e->arena.size(); e->ec.ctr = e->ctr.data();
+    e->k64s.assign(slots, ~0ull); e->k64c.assign(slots, 0); e->k64f.assign(slots, ~0ull);
+    e->ec.k64_slots = e->k64s.data(); e->ec.k64_count = e->k64c.data(); e->ec.k64_first = e->k64f.data(); e->ec.k64_mask = slots - 1;
     return e;
 }
 void emu_destroy(void *h) { delete (Emu *)h; }
@@ -59,9 +62,18 @@ void emu_destroy(void *h) { delete (Emu *)h; }
 void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t n)
 {
     Emu *e = (Emu *)h;
-    build_index(e->ix, seqs, offs, n, e->run.miss, e->plan.fast_fixed ? e->run.length : 0);
+    int packed_len = e->plan.fast_fixed ? e->run.length : 0;
+    if (e->plan.fast_anchor) {
+        if (e->run.has_up && e->run.has_down) {
+            std::vector<uint32_t> hist(F2Q_REG_MAXLEN + 1, 0);
+            for (uint32_t i = 0; i < n; i++) { uint32_t l = offs[i + 1] - offs[i]; if (l >= 1 && l <= F2Q_REG_MAXLEN) hist[l]++; }
+            packed_len = (int)(std::max_element(hist.begin(), hist.end()) - hist.begin());
+        } else packed_len = e->run.length;
+    }
+    build_index(e->ix, seqs, offs, n, e->run.miss, packed_len);
     bind_lib(e);
     e->plan.inband_n = e->plan.fast_fixed && e->ix.n_irregular == 0;
+    if (e->ix.n_irregular) e->plan.fast_anchor = false;
 }
 
 // the same two-stream split the library does: packed tiles through fixed_lane, the rest through general_read
@@ -75,7 +87,68 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
     Accum acc{e->acc.data(), e->acc.data() + e->ix.n_features, nullptr, nullptr};
     PackedBlock pb{};
     pb.n_tiles = hp.n_tiles; pb.wb = hp.wb; pb.wq = hp.wq; pb.rmax = hp.rmax; pb.n_slots = (uint64_t)hp.n_tiles * F2Q_TILE;
-    pb.bases = hp.bases.data(); pb.qual = hp.qual.data(); pb.len = hp.len.data();
+    pb.bases = hp.bases.data(); pb.qual = hp.qual.data(); pb.len = hp.len.data(); pb.planar_nw = hp.planar_nw;
+    const std::vector<uint32_t> &hp_index = hp.c_index;
+    if (hp.planar_nw) {
+        // the anchored kernel's per-lane sequence (k_count_anchor), NW = 3 or 5, KB = plan.kb
+        auto lane_fn = [&](auto nwc, auto kbc, uint32_t t, uint32_t lane) {
+            constexpr int NW = decltype(nwc)::value, KB = decltype(kbc)::value, NQW = 8 * NW;
+            const uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + lane];
+            if (l == F2Q_LEN_SKIP) return;
+            uint32_t LO[NW], HI[NW], Q[NQW];
+            const uint32_t *bp = pb.bases + (uint64_t)t * pb.wb * F2Q_TILE + lane;
+            const uint32_t *qp = pb.qual + (uint64_t)t * pb.wq * F2Q_TILE + lane;
+            for (int w = 0; w < NW; w++) { LO[w] = bp[(uint64_t)w * F2Q_TILE]; HI[w] = bp[(uint64_t)(NW + w) * F2Q_TILE]; }
+            for (int i = 0; i < NQW; i++) Q[i] = qp[(uint64_t)((uint32_t)i < pb.wq ? i : pb.wq - 1) * F2Q_TILE];
+            const int r = (int)l;
+            const unsigned long long gi = e->reads_seen + hp_index[(uint64_t)t * F2Q_TILE + lane];
+            uint32_t FW[NW], FU[NW], FD[NW];
+            fail_vectors3<NW, NQW>(Q, e->run.thr, e->run.thr_up, e->run.thr_down, FW, FU, FD);
+            const AnchorWin aw = anchor_window<NW, KB, KB>(e->run, LO, HI, r, FU, FD, FW);
+            const int L = aw.end - aw.start;
+            const bool ecm = e->run.mode == 1;
+            if (aw.ok == 0) { acc.stats[4]++; acc.stats[0]++; }
+            else if (aw.ok == 2 || L < 1 || L > (ecm ? F2Q_EC64_MAXLEN : F2Q_REG_MAXLEN)) {
+                uint8_t sq[F2Q_ANCHOR_MAXLEN], ql[F2Q_ANCHOR_MAXLEN];
+                for (int i = 0; i < r; i++) {
+                    sq[i] = (uint8_t)"ACGT"[((LO[i >> 5] >> (i & 31)) & 1u) | (((HI[i >> 5] >> (i & 31)) & 1u) << 1)];
+                    ql[i] = (uint8_t)((Q[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                }
+                general_read<const uint8_t *>(e->run, e->lib, e->ec, acc, sq, r, ql, r, gi, acc.stats);
+            } else {
+                const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
+                acc.stats[0]++;
+                if (ecm) { ec64_insert(e->ec, key, L, gi); acc.stats[1]++; }
+                else {
+                    uint32_t idx = 0; int res;
+                    if (L == (int)e->lib.pk.len) {
+                        int ex = packed_exact(e->lib, key);
+                        if (ex >= 0) { res = R_PERFECT; idx = (uint32_t)ex; }
+                        else if (e->run.miss > 0) res = packed_near_decide(e->run, e->lib, key, 0u, idx);
+                        else res = R_NONALIGNED;
+                    } else {
+                        int ex = lib_exact(e->lib, key, L);
+                        if (ex >= 0) { res = R_PERFECT; idx = (uint32_t)ex; }
+                        else {
+                            MinTrack tt; tt.init(e->run.miss);
+                            if (e->run.miss > 0) lib_near(e->lib, key, L, 0ull, tt);
+                            if (tt.cnt == 1) { res = R_IMPERFECT; idx = tt.idx; } else res = R_NONALIGNED;
+                        }
+                    }
+                    if (res == 1 || res == 2) acc.counts[idx]++;
+                    acc.stats[res]++;
+                }
+            }
+        };
+        for (uint32_t t = 0; t < hp.n_tiles; t++)
+            for (uint32_t lane = 0; lane < F2Q_TILE; lane++) {
+                if (hp.planar_nw == 3 && e->plan.kb == 1) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 1>(), t, lane);
+                else if (hp.planar_nw == 3) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 3>(), t, lane);
+                else if (e->plan.kb == 1) lane_fn(std::integral_constant<int, 5>(), std::integral_constant<int, 1>(), t, lane);
+                else lane_fn(std::integral_constant<int, 5>(), std::integral_constant<int, 3>(), t, lane);
+            }
+        e->anchor_reads += hp.n_clean;
+    } else {
     const bool v2 = e->use_v2 && e->lib.pk.len == (uint32_t)e->run.length && e->lib.pk.len > 0 && e->lib.n_irregular == 0;
     if (v2) {
         // the v2 kernel's per-lane sequence: 4 reads per lane from 16-byte row loads, packed tables
@@ -133,6 +206,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             if (res == 1 || res == 2) acc.counts[idx]++;
             if (res) { acc.stats[0]++; acc.stats[res]++; }
         }
+    }
     for (size_t g = 0; g < hp.g_len.size(); g++) {
         const uint8_t *seq = hp.raw.data() + hp.g_off[g];
         general_read(e->run, e->lib, e->ec, acc, seq, (int)hp.g_len[g], seq + hp.g_len[g], (int)hp.g_qlen[g],
@@ -154,11 +228,21 @@ void emu_read_counts(void *h, int64_t *counts, int64_t *stats, uint64_t *fast, u
 void emu_set_read_base(void *h, uint64_t b) { ((Emu *)h)->reads_seen = b; }
 void emu_use_v2(void *h, int on) { ((Emu *)h)->use_v2 = on; }
 uint64_t emu_v2_reads(void *h) { return ((Emu *)h)->v2_reads; }
-uint64_t emu_ec_n(void *h) { return ((Emu *)h)->ctr[0]; }
+uint64_t emu_anchor_reads(void *h) { return ((Emu *)h)->anchor_reads; }
+// entries: first the byte-string table, then the occupied slots of the single-word table
+static std::vector<size_t> k64_live(Emu *e) { std::vector<size_t> v; for (size_t i = 0; i < e->k64s.size(); i++) if (e->k64s[i] != ~0ull) v.push_back(i); return v; }
+uint64_t emu_ec_n(void *h) { Emu *e = (Emu *)h; return e->ctr[0] + k64_live(e).size(); }
 uint64_t emu_ec_overflow(void *h) { return ((Emu *)h)->ctr[2]; }
 void emu_ec_get(void *h, uint64_t e_, char *key, uint32_t *len, int64_t *count, uint64_t *first)
 {
     Emu *e = (Emu *)h;
+    if (e_ >= e->ctr[0]) {
+        const size_t s = k64_live(e)[e_ - e->ctr[0]];
+        const unsigned long long k = e->k64s[s];
+        *len = (uint32_t)(k >> 58); *count = (int64_t)e->k64c[s]; *first = e->k64f[s];
+        for (uint32_t j = 0; j < *len; j++) key[j] = "ACGT"[(k >> (2 * j)) & 3];
+        return;
+    }
     *len = e->ent_len[e_]; *count = (int64_t)e->ent_count[e_]; *first = e->ent_first[e_];
     memcpy(key, (const uint8_t *)(e->arena.data() + e->ent_off[e_]), *len);
 }

@@ -43,6 +43,8 @@ def lib():
         L.emu_use_v2.argtypes = [vp, C.c_int]
         L.emu_v2_reads.restype = C.c_uint64
         L.emu_v2_reads.argtypes = [vp]
+        L.emu_anchor_reads.restype = C.c_uint64
+        L.emu_anchor_reads.argtypes = [vp]
         L.emu_ec_n.restype = C.c_uint64
         L.emu_ec_n.argtypes = [vp]
         L.emu_ec_overflow.restype = C.c_uint64
@@ -76,6 +78,9 @@ class Emu:
 
     def v2_reads(self):
         return lib().emu_v2_reads(self._h)
+
+    def anchor_reads(self):
+        return lib().emu_anchor_reads(self._h)
 
     def read(self):
         counts = (C.c_int64 * max(self.n, 1))()

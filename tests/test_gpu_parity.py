@@ -167,3 +167,83 @@ def test_odd_symbols_in_the_window_gpu(P, miss):
             counts, stats = c.read_counts()
             assert list(stats) == o.stats() and list(counts) == o.counts()
             assert (t["general_reads"] == 0) == (lib is guides)
+
+
+UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+
+
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("anchors", ["both", "up", "down"])
+@pytest.mark.parametrize("ms,qs", [(0, 30), (1, 30), (2, 12), (3, 41)])
+def test_packed_anchor_kernel_vs_oracle(P, mode, anchors, ms, qs):
+    guides = synth.make_library(300, 20, 900 + ms)
+    spec = dict(seed=ms * 7 + qs, n_reads=30000, read_len=150, cassette=True, up=UP, down=DOWN, max_offset=110,
+                p_sub=0.2, p_lowq=0.15, p_n=0.02)
+    kw = dict(mode=mode, miss=1, length=20, miss_search_up=ms, miss_search_down=ms, qual_up=qs, qual_down=30)
+    if anchors in ("both", "up"):
+        kw["upstream"] = UP
+    if anchors in ("both", "down"):
+        kw["downstream"] = DOWN
+    with P.Counter(features=guides, miss=1) as gen:
+        fq = bytearray(gen.synth_fastq(**spec))
+    import random
+    rng = random.Random(5)
+    pos = 0
+    while True:                                   # damage some anchors / qualities in place (lines keep their length)
+        a = fq.find(b"\n", pos) + 1
+        b = fq.find(b"\n", a)
+        if a <= 0 or b < 0:
+            break
+        qa = fq.find(b"\n", b + 1) + 1
+        qb = fq.find(b"\n", qa)
+        if rng.random() < 0.5:
+            for _ in range(rng.randint(1, 3)):
+                fq[a + rng.randrange(b - a)] = rng.choice(b"ACGT")
+            fq[qa + rng.randrange(qb - qa)] = rng.choice(b"#+5:?")
+        pos = qb + 1
+    fq = bytes(fq)
+    orc = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(guides)], **kw) if mode == "C" else None
+    if mode == "EC":
+        orc = O.Oracle(**kw)
+        orc.count_fastq(fq)
+    with P.Counter(features=guides if mode == "C" else None, **kw) as c:
+        _, t = c.count_block(fq, want_timing=True)
+        counts, stats = c.read_counts()
+        assert list(stats) == orc.stats()
+        assert t["fast_reads"] > 0.9 * t["reads"]
+        if mode == "C":
+            assert list(counts) == orc.counts()
+        else:
+            assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+        # the device-generated block of the undamaged spec agrees with its own host FASTQ
+        c.reset()
+        with P.Counter(features=guides, miss=1) as gen:
+            clean_fq = bytes(gen.synth_fastq(**spec))
+        o2 = O.Oracle(features=[(str(i), s) for i, s in enumerate(guides)] if mode == "C" else None, **kw)
+        o2.count_fastq(clean_fq)
+        blk = c.synth_create(guides=guides, **spec)
+        c.count_resident(blk)
+        counts2, stats2 = c.read_counts()
+        assert list(stats2) == o2.stats()
+        if mode == "C":
+            assert list(counts2) == o2.counts()
+        else:
+            assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o2.keys(), o2.counts()))
+
+
+def test_ec_table_growth_across_blocks(P):
+    """many distinct keys over several blocks: both Extract+Count tables are re-hashed on the device"""
+    guides = synth.make_library(60000, 20, 4)
+    kw = dict(mode="EC", upstream=UP, downstream=DOWN)
+    orc = O.Oracle(**kw)
+    with P.Counter(**kw) as c:
+        for blk in range(4):
+            with P.Counter(features=guides, miss=1) as gen:
+                fq = bytes(gen.synth_fastq(seed=50 + blk, n_reads=40000, read_len=150, cassette=True, up=UP, down=DOWN,
+                                           p_rand=0.5))
+            fq = sprinkle_symbols(fq, blk, rate=0.002)        # a few keys with odd symbols -> byte-string table
+            orc.count_fastq(fq)
+            c.count_block(fq)
+        counts, stats = c.read_counts()
+        assert list(stats) == orc.stats()
+        assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))

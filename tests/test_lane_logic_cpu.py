@@ -110,3 +110,63 @@ def test_odd_symbols_in_the_window(miss):
             counts, stats, fast, gen = e.read()
             assert stats == o.stats() and counts == o.counts()
             assert (gen == 0) == (lib is guides)
+
+
+UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+
+
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("anchors", ["both", "up", "down"])
+@pytest.mark.parametrize("ms,qs", [(0, 30), (1, 30), (2, 30), (1, 12), (3, 41)])
+def test_packed_anchor_logic_vs_oracle(mode, anchors, ms, qs):
+    """the bit-plane anchored lane logic (planar tiles, bit-sliced mismatch counters, fail vectors)"""
+    guides = synth.make_library(200, 20, 900 + ms)
+    spec = synth.Spec(seed=ms * 7 + qs, n_reads=2500, read_len=150, cassette=True, up=UP, down=DOWN, max_offset=110,
+                      p_sub=0.2, p_lowq=0.15, p_n=0.02)
+    fq = synth.make_fastq(spec, guides)
+    # damage some anchors and some anchor qualities so that msu/msd and qsu/qsd matter
+    import random
+    rng = random.Random(5)
+    lines = fq.split(b"\n")
+    for i in range(1, len(lines), 4):
+        if rng.random() < 0.5:
+            b = bytearray(lines[i]); q = bytearray(lines[i + 2])
+            for _ in range(rng.randint(1, 3)):
+                p = rng.randrange(len(b)); b[p] = rng.choice(b"ACGT")
+            q[rng.randrange(len(q))] = rng.choice(b"#+5:?")
+            lines[i], lines[i + 2] = bytes(b), bytes(q)
+    fq = b"\n".join(lines)
+    kw = dict(mode=mode, miss=1, length=20, miss_search_up=ms, miss_search_down=ms, qual_up=qs, qual_down=30)
+    if anchors in ("both", "up"):
+        kw["upstream"] = UP
+    if anchors in ("both", "down"):
+        kw["downstream"] = DOWN
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(guides)] if mode == "C" else None, **kw)
+    o.count_fastq(fq)
+    e = Emu(features=guides if mode == "C" else None, **kw)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats()
+    assert e.anchor_reads() == fast and fast > 0.9 * stats[0]           # the packed path did the work
+    if mode == "C":
+        assert counts == o.counts()
+    else:
+        assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
+
+
+def test_packed_anchor_short_and_ragged_reads():
+    guides = synth.make_library(50, 12, 77)
+    parts = []
+    for n, rl in ((300, 40), (300, 96), (300, 97), (200, 160), (100, 161), (50, 13)):
+        parts.append(synth.make_fastq(synth.Spec(seed=rl, n_reads=n, read_len=rl, cassette=True, up="ACGTAC", down="TTGCA",
+                                                 max_offset=max(0, rl - 30)), guides))
+    fq = b"".join(parts)
+    for kw in (dict(upstream="ACGTAC", downstream="TTGCA", miss_search_up=1), dict(upstream="ACGTAC", length=12),
+               dict(downstream="TTGCA", length=12, miss_search_down=2)):
+        o = O.Oracle(features=[(str(i), s) for i, s in enumerate(guides)], miss=1, **kw)
+        o.count_fastq(fq)
+        e = Emu(features=guides, miss=1, **kw)
+        e.count_block(fq)
+        counts, stats, fast, gen = e.read()
+        assert stats == o.stats() and counts == o.counts()
+        assert 100 <= gen < 125        # the 161-base reads exceed the packed kernel; so do the few reads holding an N
