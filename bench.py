@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--workload", default="cfg3_50M_10k_m1", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (rehearsal)")
     ap.add_argument("--miss", type=int, default=None, help="override --m (experiments)")
     ap.add_argument("--phred", type=int, default=30, help="override --ph (experiments)")
     ap.add_argument("--read-len", type=int, default=150, help="override the read length (experiments)")
@@ -72,8 +73,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the counting path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     pkg = importlib.import_module("2fast2q_amd")
     w = dict(WORKLOADS[a.workload])
     if a.reads:
@@ -105,7 +109,7 @@ def main():
 
     def step():
         t = c.count_resident(blk)          # launches on the context's stream, waits on its HIP events
-        if world > 1:
+        if use_dist:
             with torch.cuda.stream(stream):
                 dist.all_reduce(acc)
         return t
@@ -113,18 +117,19 @@ def main():
     for _ in range(a.warmup):
         c.reset(); step()
     kern_ms = []
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        c.reset()                              # each step is a whole job: zeroed accumulators -> count -> all-reduce
         kern_ms.append(step()["kernel_ms"])
     stream.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -147,8 +152,14 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, guides, w["miss"])
         print(json.dumps(out))
+    if use_dist:
+        # every rank must hold the whole-job result after the last step's all-reduce
+        counts, stats = c.read_counts()
+        chk = torch.tensor([int(stats[0])], device="cuda", dtype=torch.int64)
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+        assert int(chk.item()) == int(stats[0]) == n * world, (int(stats[0]), n * world)
     blk.free(); c.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
