@@ -56,8 +56,9 @@ struct RunDev {
     uint8_t up[F2Q_DEV_MAX_ITER][F2Q_ANCHOR_MAX];
     uint8_t down[F2Q_DEV_MAX_ITER][F2Q_ANCHOR_MAX];
     // packed anchored path (one --us/--ds pair, ACGT-only anchors of 1..32 bases): 2-bit codes of pair 0
-    int32_t anchors_packed;            // 1: up2/down2 are valid
-    uint8_t up2[32], down2[32];
+    int32_t anchors_packed;            // 1: up_codes/down_codes are valid
+    int32_t pad_;
+    uint64_t up_codes, down_codes;     // symbol j = (codes >> 2j) & 3  -- one scalar load, no per-symbol memory access
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -859,10 +860,28 @@ F2Q_HD uint32_t range_mask32(int lo, int hi)
     return upper & (lo >= 32 ? 0u : (~0u << lo));
 }
 
-// positions p at which an s-symbol anchor (2-bit codes) sits within k mismatches; KB = counter bits
-// (0: exact search, 1: k <= 1, 2: k <= 3, 3: k <= 7)
+// one anchor symbol: add (plane >> j) into the bit-sliced saturating counters
 template <int NW, int KB>
-F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint8_t *codes, int s, int k,
+F2Q_HD void anchor_step(const uint32_t (&P)[NW], int j, uint32_t (&cnt)[KB > 0 ? KB : 1][NW], uint32_t (&ovf)[NW])
+{
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint32_t x = funnel_shr(w + 1 < NW ? P[w + 1] : ~0u, P[w], j);   // beyond the planes: "differs"
+        if (KB == 0) ovf[w] |= x;
+        else {
+#pragma unroll
+            for (int b = 0; b < KB; b++) { uint32_t c = cnt[b][w] & x; cnt[b][w] ^= x; x = c; }
+            ovf[w] |= x;
+        }
+    }
+}
+
+// positions p at which an s-symbol anchor (2-bit codes) sits within k mismatches; KB = counter bits
+// (0: exact search, 1: k <= 1, 3: k <= 7).  For each of the four symbols the "base differs from it"
+// plane is formed once, then shifted and counted for every anchor position holding that symbol, so
+// only one plane is live at a time.  All loops and branches are wave-uniform.
+template <int NW, int KB>
+F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], uint64_t codes, int s, int k,
                         uint32_t (&hit)[NW])
 {
     uint32_t cnt[KB > 0 ? KB : 1][NW], ovf[NW];
@@ -872,20 +891,14 @@ F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], cons
 #pragma unroll
         for (int b = 0; b < (KB > 0 ? KB : 1); b++) cnt[b][w] = 0;
     }
-    for (int j = 0; j < s; j++) {                       // wave-uniform loop
-        const uint32_t la = (codes[j] & 1) ? ~0u : 0u, ha = (codes[j] & 2) ? ~0u : 0u;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const uint32_t lo = funnel_shr(w + 1 < NW ? LO[w + 1] : 0u, LO[w], j);
-            const uint32_t hi = funnel_shr(w + 1 < NW ? HI[w + 1] : 0u, HI[w], j);
-            uint32_t x = (lo ^ la) | (hi ^ ha);          // 1 = base p+j differs from anchor symbol j
-            if (KB == 0) ovf[w] |= x;
-            else {
+    for (int c = 0; c < 4; c++) {
+        const uint32_t la = (c & 1) ? ~0u : 0u, ha = (c & 2) ? ~0u : 0u;
+        uint32_t P[NW];
 #pragma unroll
-                for (int b = 0; b < KB; b++) { uint32_t c = cnt[b][w] & x; cnt[b][w] ^= x; x = c; }
-                ovf[w] |= x;
-            }
-        }
+        for (int w = 0; w < NW; w++) P[w] = (LO[w] ^ la) | (HI[w] ^ ha);      // 1 = base is not symbol c
+        for (int j = 0; j < s; j++)
+            if ((int)((codes >> (2 * j)) & 3ull) == c) anchor_step<NW, KB>(P, j, cnt, ovf);
     }
     // hit = count <= k (bit-sliced compare against the wave-uniform k) and no overflow
 #pragma unroll
@@ -923,7 +936,7 @@ F2Q_HD bool any_in_range(const uint32_t (&F)[NW], int a, int b)
     return acc != 0;
 }
 
-// L (<= 32) bits of a plane starting at bit `start`
+// L (<= 32) bits of a plane starting at bit `start` (start + L may pass the end: zeros)
 template <int NW>
 F2Q_HD uint32_t plane_extract(const uint32_t (&P)[NW], int start, int L)
 {
@@ -954,6 +967,18 @@ F2Q_HD void fail_vector(const uint32_t (&Q)[NQW], int thr, uint32_t (&F)[NW])
         }
     }
 }
+
+// Phred fail bits of 32 bases from their 8 quality words (bytes < 128); add_hi == 0: rule off
+F2Q_HD uint32_t fail_word8(const uint32_t (&q)[8], uint32_t add_hi)
+{
+    if (!add_hi) return 0u;
+    uint32_t f = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        f |= ((((qfail4(q[i], 0x5F5F5F5Fu, add_hi, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);
+    return f;
+}
+F2Q_HD uint32_t phred_add_hi(int thr) { return thr >= 33 ? (uint32_t)(127 - thr) * 0x01010101u : 0u; }
 
 // the three per-base fail vectors of an anchored run (--ph window, --qsu, --qsd) in ONE pass over the
 // quality words, so that each word is dead after its use; equal thresholds share the work
@@ -987,6 +1012,13 @@ struct AnchorWin { int ok; int start, end; };      // ok: 0 = no window (counts 
 
 // sequence_tinder (:215-285) + the window Phred test (:357) on bit-planes.  FU/FD/FW: fail vectors
 // for --qsu / --qsd / --ph (they may alias when the thresholds coincide).
+// any set bit of F in [a, a+len), len <= 32 (anchors are <= 32 symbols, fast-path windows <= 31)
+template <int NW>
+F2Q_HD bool any_fail_short(const uint32_t (&F)[NW], int a, int len)
+{
+    return len > 0 && plane_extract<NW>(F, a, len) != 0u;
+}
+
 template <int NW, int KBU, int KBD>
 F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], int r,
                                const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW])
@@ -996,33 +1028,33 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
     int start, end;
     if (run.has_up && run.has_down) {
         uint32_t hu[NW], hd[NW];
-        anchor_hits<NW, KBU>(LO, HI, run.up2, su, run.msu, hu);
+        anchor_hits<NW, KBU>(LO, HI, run.up_codes, su, run.msu, hu);
         const int pu = first_hit<NW>(hu, 0, r - su);
         if (pu < 0) return out;
-        anchor_hits<NW, KBD>(LO, HI, run.down2, sd, run.msd, hd);
+        anchor_hits<NW, KBD>(LO, HI, run.down_codes, sd, run.msd, hd);
         const int pd = first_hit<NW>(hd, pu + su, r - sd);
         if (pd < 0) return out;
-        if (any_in_range<NW>(FU, pu, pu + su) || any_in_range<NW>(FD, pd, pd + sd)) return out;
+        if (any_fail_short<NW>(FU, pu, su) || any_fail_short<NW>(FD, pd, sd)) return out;
         start = pu + su; end = pd;
     } else if (run.has_up) {
         uint32_t hu[NW];
-        anchor_hits<NW, KBU>(LO, HI, run.up2, su, run.msu, hu);
+        anchor_hits<NW, KBU>(LO, HI, run.up_codes, su, run.msu, hu);
         const int pu = first_hit<NW>(hu, 0, r - su);
         if (pu < 0) return out;
-        if (any_in_range<NW>(FU, pu, pu + su)) return out;
+        if (any_fail_short<NW>(FU, pu, su)) return out;
         start = pu + su; end = start + run.length;
         if (run.length < 0) { out.ok = 2; return out; }
         if (end > r) end = r;                                   // Python slice clipping (:354)
     } else {
         uint32_t hd[NW];
-        anchor_hits<NW, KBD>(LO, HI, run.down2, sd, run.msd, hd);
+        anchor_hits<NW, KBD>(LO, HI, run.down_codes, sd, run.msd, hd);
         const int pd = first_hit<NW>(hd, 0, r - sd);
         if (pd < 0) return out;
-        if (any_in_range<NW>(FD, pd, pd + sd)) return out;
+        if (any_fail_short<NW>(FD, pd, sd)) return out;
         start = pd - run.length; end = pd;
         if (start < 0 || run.length < 0) { out.ok = 2; return out; }   // negative-index slice: rare, slow routine
     }
-    if (any_in_range<NW>(FW, start, end)) return out;           // window Phred test (:357)
+    if (end - start <= 32 ? any_fail_short<NW>(FW, start, end - start) : any_in_range<NW>(FW, start, end)) return out;   // :357
     out.ok = 1; out.start = start; out.end = end;
     return out;
 }

@@ -193,7 +193,7 @@ struct PackPlan {
     int from = 0;                  // ... and only [from, need) is ever looked at
     bool inband_n = false;         // non-ACGT window symbols travel as flag bits (all-ACGT library only)
     bool fast_anchor = false;      // one --us/--ds pair with ACGT anchors: packed bit-plane path
-    int kb = 1;                    // counter bits of the anchor search (1: k <= 1, 3: k <= 7)
+    int kb = 1;                    // counter bits of the anchor search (0: exact, 1: k <= 1, 3: k <= 7)
 };
 #define F2Q_ANCHOR_MAXLEN 160      // longest read the packed anchored kernel holds in registers (5 x 32 bases)
 
@@ -206,7 +206,7 @@ inline PackPlan make_plan(const RunDev &run)
     pl.from = pl.fast_fixed ? run.start[0] : 0;
     pl.fast_anchor = !run.fixed && run.n_iter == 1 && run.anchors_packed && run.msu >= 0 && run.msd >= 0 &&
                      run.msu <= 7 && run.msd <= 7 && run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN;
-    pl.kb = (run.msu <= 1 && run.msd <= 1) ? 1 : 3;
+    pl.kb = (run.msu == 0 && run.msd == 0) ? 0 : (run.msu <= 1 && run.msd <= 1) ? 1 : 3;
     return pl;
 }
 
@@ -388,7 +388,7 @@ inline int fill_run(const f2q_params &p, RunDev &r, std::string &err)
         for (int k = 0; k < l; k++) {
             uint32_t c = base_code(side ? r.down[0][k] : r.up[0][k]);
             if (c > 3u) { r.anchors_packed = 0; break; }
-            (side ? r.down2 : r.up2)[k] = (uint8_t)c;
+            (side ? r.down_codes : r.up_codes) |= (uint64_t)c << (2 * k);
         }
     }
     return F2Q_OK;

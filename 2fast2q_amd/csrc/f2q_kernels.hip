@@ -322,7 +322,8 @@ __device__ __noinline__ void anchor_slow(const RunDev *run, const LibDev *lib, c
     general_read<const uint8_t *>(*run, *lib, *ec, *acc, seq, r, qual, r, read_index, st);
 }
 
-template <int NW, int KB, bool EC, bool USE_LDS>
+// SAMEQ: --qsu == --qsd == --ph (the default), one fail vector serves all three Phred tests
+template <int NW, int KB, bool EC, bool USE_LDS, bool SAMEQ>
 __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *__restrict__ runp,
                                                                   const LibDev *__restrict__ libp, EcDev ec,
                                                                   PackedBlock pb, Accum acc, uint64_t read_base)
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     uint32_t q_head = 0;
     const bool do_near = run.miss > 0;
     const int pk_len = (int)lib.pk.len;
+    const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
     unsigned long long st[5] = {0, 0, 0, 0, 0};
 
     auto count_hit = [&](uint32_t idx) {
@@ -353,28 +355,60 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
         const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + tid;
         const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + tid;
-        uint32_t LO[NW], HI[NW], Q[NQW];
+        const uint32_t l = pb.len ? gp(pb.len)[(uint64_t)tile * F2Q_TILE + tid] : pb.rmax;
+        uint32_t LO[NW], HI[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             LO[w] = __builtin_nontemporal_load(bp + (uint64_t)w * F2Q_TILE);
             HI[w] = __builtin_nontemporal_load(bp + (uint64_t)(NW + w) * F2Q_TILE);
         }
+        // quality words -> per-base fail vectors.  All 8*NW loads are issued together (one memory round trip);
+        // the scheduling barrier keeps the compiler from stretching their live ranges into the anchor search.
+        uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW];
+        {
+            uint32_t Q[NQW];
 #pragma unroll
-        for (int i = 0; i < NQW; i++) {
-            const uint32_t row = (uint32_t)i < pb.wq ? (uint32_t)i : pb.wq - 1u;
-            Q[i] = __builtin_nontemporal_load(qp + (uint64_t)row * F2Q_TILE);
+            for (int i = 0; i < NQW; i++)
+                Q[i] = __builtin_nontemporal_load(qp + (uint64_t)((uint32_t)i < pb.wq ? (uint32_t)i : pb.wq - 1u) * F2Q_TILE);
+#pragma unroll
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q8[i] = Q[8 * cw + i];
+                FW[cw] = fail_word8(q8, ah_w);
+                if (!SAMEQ) { FU[cw] = fail_word8(q8, ah_u); FD[cw] = fail_word8(q8, ah_d); }
+            }
         }
-        const uint32_t l = pb.len ? gp(pb.len)[(uint64_t)tile * F2Q_TILE + tid] : pb.rmax;
+        __builtin_amdgcn_sched_barrier(0);
         if (l != F2Q_LEN_SKIP) {
             const int r = (int)l;
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
             const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
-            uint32_t FW[NW], FU[NW], FD[NW];
-            fail_vectors3<NW, NQW>(Q, run.thr, run.thr_up, run.thr_down, FW, FU, FD);
-            const AnchorWin aw = anchor_window<NW, KB, KB>(run, LO, HI, r, FU, FD, FW);
+            AnchorWin aw;
+            if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, LO, HI, r, FW, FW, FW);
+            else aw = anchor_window<NW, KB, KB>(run, LO, HI, r, FU, FD, FW);
             const int L = aw.end - aw.start;
             if (aw.ok == 0) { st[4]++; st[0]++; }
-            else if (aw.ok == 2 || L < 1 || L > (EC ? F2Q_EC64_MAXLEN : F2Q_REG_MAXLEN)) {
+            else if (aw.ok == 1 && !EC && (L < 1 || L > F2Q_REG_MAXLEN)) {
+                // Counter mode, all-ACGT library of <= 31-base features (the packed path's precondition): an empty
+                // or longer window passed its Phred test but can equal or approach no feature (:683) -> not aligned
+                st[3]++; st[0]++;
+            } else if (aw.ok == 1 && EC && L > F2Q_EC64_MAXLEN) {
+                // Extract+Count key too long for the single-word table: decode the window and use the byte-string table
+                uint8_t kb[32 * NW];
+#pragma unroll
+                for (int cw = 0; cw < NW; cw++) {
+                    const int off = 32 * cw, n = L - off < 32 ? L - off : 32;
+                    if (n > 0) {
+                        const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
+                        for (int j = 0; j < n; j++) kb[off + j] = (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
+                    }
+                }
+                KeyView kv; kv.seq = kb; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = L; kv.len = L;
+                ec_insert(ec, kv, gi);
+                st[1]++; st[0]++;
+            } else if (aw.ok == 2) {
+                // negative-index slices (down-only anchor near the read start, negative --l): byte-exact routine
                 unsigned long long st2[5] = {0, 0, 0, 0, 0};
                 const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
                 anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st2);
@@ -966,20 +1000,26 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             if (lds) { acc.slab = c->slab_d; acc.stat_slab = c->stat_slab_d; }
         }
         const int nw = (int)b->pb.planar_nw, kb = c->plan.kb;
-#define F2Q_LAUNCH_AN(NW_, KB_)                                                                                      \
+        const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
+#define F2Q_LAUNCH_AN2(NW_, KB_, SQ_)                                                                                \
         do {                                                                                                         \
-            if (ecm) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, true, false>), dim3(grid), dim3(F2Q_AN_THREADS), shmem, \
-                                        c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);            \
-            else if (lds) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, true>), dim3(grid), dim3(F2Q_AN_THREADS),   \
-                                             shmem, c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen); \
-            else hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, false>), dim3(grid), dim3(F2Q_AN_THREADS), shmem,    \
-                                    c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);                \
+            if (ecm) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, true, false, SQ_>), dim3(grid), dim3(F2Q_AN_THREADS),   \
+                                        shmem, c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);     \
+            else if (lds) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, true, SQ_>), dim3(grid),               \
+                                             dim3(F2Q_AN_THREADS), shmem, c->stream, c->run_d, c->lib_d, c->ec,      \
+                                             b->pb, acc, c->reads_seen);                                             \
+            else hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, false, SQ_>), dim3(grid), dim3(F2Q_AN_THREADS),  \
+                                    shmem, c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);         \
         } while (0)
-        if (nw == 3 && kb == 1) F2Q_LAUNCH_AN(3, 1);
+#define F2Q_LAUNCH_AN(NW_, KB_) do { if (sameq) F2Q_LAUNCH_AN2(NW_, KB_, true); else F2Q_LAUNCH_AN2(NW_, KB_, false); } while (0)
+        if (nw == 3 && kb == 0) F2Q_LAUNCH_AN(3, 0);
+        else if (nw == 3 && kb == 1) F2Q_LAUNCH_AN(3, 1);
         else if (nw == 3) F2Q_LAUNCH_AN(3, 3);
+        else if (kb == 0) F2Q_LAUNCH_AN(5, 0);
         else if (kb == 1) F2Q_LAUNCH_AN(5, 1);
         else F2Q_LAUNCH_AN(5, 3);
 #undef F2Q_LAUNCH_AN
+#undef F2Q_LAUNCH_AN2
         HIPC(c, hipGetLastError());
         launches++;
         if (lds && c->lib_h.n_features) {

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (rehearsal)")
     ap.add_argument("--miss", type=int, default=None, help="override --m (experiments)")
     ap.add_argument("--phred", type=int, default=30, help="override --ph (experiments)")
+    ap.add_argument("--ms", type=int, default=1, help="--msu/--msd of the anchored workloads (experiments)")
     ap.add_argument("--read-len", type=int, default=150, help="override the read length (experiments)")
     ap.add_argument("--p-n", type=float, default=0.005, help="share of reads with an N in the window (experiments)")
     a = ap.parse_args()
@@ -88,7 +89,7 @@ def main():
     n = w["n_reads"]
     if w.get("anchored"):
         # the generator needs the library; an EC context has none, so generate through a Counter context's spec
-        akw = dict(upstream=UP, downstream=DOWN, miss_search_up=1, miss_search_down=1)
+        akw = dict(upstream=UP, downstream=DOWN, miss_search_up=a.ms, miss_search_down=a.ms)
         c = pkg.Counter(features=None if w.get("ec") else guides, mode="EC" if w.get("ec") else "C", miss=w["miss"],
                         phred=a.phred, device=local, **akw)
         spec = dict(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=a.read_len, p_n=a.p_n, cassette=True, up=UP,

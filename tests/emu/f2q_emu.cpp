@@ -108,7 +108,21 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             const int L = aw.end - aw.start;
             const bool ecm = e->run.mode == 1;
             if (aw.ok == 0) { acc.stats[4]++; acc.stats[0]++; }
-            else if (aw.ok == 2 || L < 1 || L > (ecm ? F2Q_EC64_MAXLEN : F2Q_REG_MAXLEN)) {
+            else if (aw.ok == 1 && !ecm && (L < 1 || L > F2Q_REG_MAXLEN)) { acc.stats[3]++; acc.stats[0]++; }
+            else if (aw.ok == 1 && ecm && L > F2Q_EC64_MAXLEN) {
+                uint8_t kb[32 * NW];
+                for (int cw = 0; cw < NW; cw++) {
+                    const int off = 32 * cw, n = L - off < 32 ? L - off : 32;
+                    if (n > 0) {
+                        const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
+                        for (int j = 0; j < n; j++) kb[off + j] = (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
+                    }
+                }
+                KeyView kv; kv.seq = kb; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = L; kv.len = L;
+                ec_insert(e->ec, kv, gi);
+                acc.stats[1]++; acc.stats[0]++;
+            }
+            else if (aw.ok == 2) {
                 uint8_t sq[F2Q_ANCHOR_MAXLEN], ql[F2Q_ANCHOR_MAXLEN];
                 for (int i = 0; i < r; i++) {
                     sq[i] = (uint8_t)"ACGT"[((LO[i >> 5] >> (i & 31)) & 1u) | (((HI[i >> 5] >> (i & 31)) & 1u) << 1)];
@@ -142,7 +156,9 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
         };
         for (uint32_t t = 0; t < hp.n_tiles; t++)
             for (uint32_t lane = 0; lane < F2Q_TILE; lane++) {
-                if (hp.planar_nw == 3 && e->plan.kb == 1) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 1>(), t, lane);
+                if (hp.planar_nw == 3 && e->plan.kb == 0) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 0>(), t, lane);
+                else if (hp.planar_nw == 5 && e->plan.kb == 0) lane_fn(std::integral_constant<int, 5>(), std::integral_constant<int, 0>(), t, lane);
+                else if (hp.planar_nw == 3 && e->plan.kb == 1) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 1>(), t, lane);
                 else if (hp.planar_nw == 3) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 3>(), t, lane);
                 else if (e->plan.kb == 1) lane_fn(std::integral_constant<int, 5>(), std::integral_constant<int, 1>(), t, lane);
                 else lane_fn(std::integral_constant<int, 5>(), std::integral_constant<int, 3>(), t, lane);
