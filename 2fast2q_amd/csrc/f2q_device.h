@@ -881,8 +881,8 @@ F2Q_HD void anchor_step(const uint32_t (&P)[NW], int j, uint32_t (&cnt)[KB > 0 ?
 // plane is formed once, then shifted and counted for every anchor position holding that symbol, so
 // only one plane is live at a time.  All loops and branches are wave-uniform.
 template <int NW, int KB>
-F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], uint64_t codes, int s, int k,
-                        uint32_t (&hit)[NW])
+F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW], uint64_t codes,
+                        int s, int k, uint32_t (&hit)[NW])
 {
     uint32_t cnt[KB > 0 ? KB : 1][NW], ovf[NW];
 #pragma unroll
@@ -896,7 +896,7 @@ F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], uint
         const uint32_t la = (c & 1) ? ~0u : 0u, ha = (c & 2) ? ~0u : 0u;
         uint32_t P[NW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) P[w] = (LO[w] ^ la) | (HI[w] ^ ha);      // 1 = base is not symbol c
+        for (int w = 0; w < NW; w++) P[w] = (LO[w] ^ la) | (HI[w] ^ ha) | FLG[w];   // 1 = base is not symbol c (flagged: never)
         for (int j = 0; j < s; j++)
             if ((int)((codes >> (2 * j)) & 3ull) == c) anchor_step<NW, KB>(P, j, cnt, ovf);
     }
@@ -975,7 +975,15 @@ F2Q_HD uint32_t fail_word8(const uint32_t (&q)[8], uint32_t add_hi)
     uint32_t f = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        f |= ((((qfail4(q[i], 0x5F5F5F5Fu, add_hi, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);
+        f |= ((((qfail4(q[i] & 0x7F7F7F7Fu, 0x5F5F5F5Fu, add_hi, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);   // bit 7 = flag, not quality
+    return f;
+}
+// non-ACGT flag bits (bit 7 of the quality bytes) of 32 bases from their 8 quality words
+F2Q_HD uint32_t flag_word8(const uint32_t (&q)[8])
+{
+    uint32_t f = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) f |= (((((q[i] & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);
     return f;
 }
 F2Q_HD uint32_t phred_add_hi(int thr) { return thr >= 33 ? (uint32_t)(127 - thr) * 0x01010101u : 0u; }
@@ -1020,7 +1028,8 @@ F2Q_HD bool any_fail_short(const uint32_t (&F)[NW], int a, int len)
 }
 
 template <int NW, int KBU, int KBD>
-F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], int r,
+F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW],
+                               const uint32_t (&FLG)[NW], int r,
                                const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW])
 {
     AnchorWin out; out.ok = 0; out.start = 0; out.end = 0;
@@ -1028,17 +1037,17 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
     int start, end;
     if (run.has_up && run.has_down) {
         uint32_t hu[NW], hd[NW];
-        anchor_hits<NW, KBU>(LO, HI, run.up_codes, su, run.msu, hu);
+        anchor_hits<NW, KBU>(LO, HI, FLG, run.up_codes, su, run.msu, hu);
         const int pu = first_hit<NW>(hu, 0, r - su);
         if (pu < 0) return out;
-        anchor_hits<NW, KBD>(LO, HI, run.down_codes, sd, run.msd, hd);
+        anchor_hits<NW, KBD>(LO, HI, FLG, run.down_codes, sd, run.msd, hd);
         const int pd = first_hit<NW>(hd, pu + su, r - sd);
         if (pd < 0) return out;
         if (any_fail_short<NW>(FU, pu, su) || any_fail_short<NW>(FD, pd, sd)) return out;
         start = pu + su; end = pd;
     } else if (run.has_up) {
         uint32_t hu[NW];
-        anchor_hits<NW, KBU>(LO, HI, run.up_codes, su, run.msu, hu);
+        anchor_hits<NW, KBU>(LO, HI, FLG, run.up_codes, su, run.msu, hu);
         const int pu = first_hit<NW>(hu, 0, r - su);
         if (pu < 0) return out;
         if (any_fail_short<NW>(FU, pu, su)) return out;
@@ -1047,7 +1056,7 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
         if (end > r) end = r;                                   // Python slice clipping (:354)
     } else {
         uint32_t hd[NW];
-        anchor_hits<NW, KBD>(LO, HI, run.down_codes, sd, run.msd, hd);
+        anchor_hits<NW, KBD>(LO, HI, FLG, run.down_codes, sd, run.msd, hd);
         const int pd = first_hit<NW>(hd, 0, r - sd);
         if (pd < 0) return out;
         if (any_fail_short<NW>(FD, pd, sd)) return out;

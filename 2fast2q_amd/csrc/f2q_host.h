@@ -218,8 +218,15 @@ inline bool read_is_clean(const PackPlan &pl, const Rec &r)
     if (pl.fast_anchor) {
         // the anchor search is case-sensitive on the raw read (:337), so only upper-case ACGT reads are packed
         if (r.qlen != r.len || r.len > F2Q_ANCHOR_MAXLEN) return false;
-        for (uint32_t j = 0; j < r.len; j++)
-            if (base_code(r.seq[j]) > 3u || (r.qual[j] & 0x80)) return false;
+        for (uint32_t j = 0; j < r.len; j++) {
+            if (r.qual[j] & 0x80) return false;
+            if (base_code(r.seq[j]) > 3u) {
+                // symbols that equal no anchor/feature symbol travel as flag bits; lower-case acgt cannot (they
+                // differ from the anchors but match features after upper-casing, :337 vs :354)
+                const uint8_t c = r.seq[j];
+                if (!pl.inband_n || c == 'a' || c == 'c' || c == 'g' || c == 't') return false;
+            }
+        }
         return true;
     }
     if (!pl.fast_fixed) return false;
@@ -280,20 +287,24 @@ inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostP
         for (size_t s = 0; s < clean.size(); s++) {
             const Rec &r = recs[clean[s]];
             const size_t tile = s / F2Q_TILE, lane = s % F2Q_TILE;
-            hp.len[tile * F2Q_TILE + lane] = (uint16_t)r.len;
+            bool flagged = false;
+            for (uint32_t j = 0; j < r.len; j++) flagged |= base_code(r.seq[j]) > 3u;
+            hp.len[tile * F2Q_TILE + lane] = (uint16_t)(r.len | (flagged ? F2Q_LEN_FLAG : 0u));
             uint32_t *bp = hp.bases.data() + tile * hp.wb * F2Q_TILE + lane;
             uint32_t *qp = hp.qual.data() + tile * hp.wq * F2Q_TILE + lane;
             for (uint32_t w = 0; w * 32 < r.len; w++) {
                 uint32_t lo = 0, hi = 0;
                 for (uint32_t j = 0; j < 32 && w * 32 + j < r.len; j++) {
                     uint32_t c = base_code(r.seq[w * 32 + j]);
+                    if (c > 3u) c = 0;
                     lo |= (c & 1u) << j; hi |= ((c >> 1) & 1u) << j;
                 }
                 bp[(size_t)w * F2Q_TILE] = lo; bp[(size_t)(nw + w) * F2Q_TILE] = hi;
             }
             for (uint32_t w = 0; w * 4 < r.len; w++) {
                 uint32_t v = 0;
-                for (uint32_t j = 0; j < 4 && w * 4 + j < r.len; j++) v |= (uint32_t)r.qual[w * 4 + j] << (8 * j);
+                for (uint32_t j = 0; j < 4 && w * 4 + j < r.len; j++)
+                    v |= ((uint32_t)r.qual[w * 4 + j] | (base_code(r.seq[w * 4 + j]) > 3u ? 0x80u : 0u)) << (8 * j);
                 qp[(size_t)w * F2Q_TILE] = v;
             }
         }

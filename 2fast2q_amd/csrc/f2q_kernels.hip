@@ -318,6 +318,7 @@ __device__ __noinline__ void anchor_slow(const RunDev *run, const LibDev *lib, c
         const uint32_t lo = bp[(uint64_t)(i >> 5) * F2Q_TILE], hi = bp[(uint64_t)(nw + (i >> 5)) * F2Q_TILE];
         seq[i] = (uint8_t)"ACGT"[((lo >> (i & 31)) & 1u) | (((hi >> (i & 31)) & 1u) << 1)];
         qual[i] = (uint8_t)((qp[(uint64_t)(i >> 2) * F2Q_TILE] >> (8 * (i & 3))) & 0xFFu);
+        if (qual[i] & 0x80u) { seq[i] = (uint8_t)'N'; qual[i] &= 0x7Fu; }      // flagged: a symbol that equals nothing
     }
     general_read<const uint8_t *>(*run, *lib, *ec, *acc, seq, r, qual, r, read_index, st);
 }
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
         }
         // quality words -> per-base fail vectors.  All 8*NW loads are issued together (one memory round trip);
         // the scheduling barrier keeps the compiler from stretching their live ranges into the anchor search.
-        uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW];
+        uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW], FLG[NW];
+        const bool flagged = (l != F2Q_LEN_SKIP) && (l & F2Q_LEN_FLAG);
         {
             uint32_t Q[NQW];
 #pragma unroll
@@ -377,16 +379,17 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 for (int i = 0; i < 8; i++) q8[i] = Q[8 * cw + i];
                 FW[cw] = fail_word8(q8, ah_w);
                 if (!SAMEQ) { FU[cw] = fail_word8(q8, ah_u); FD[cw] = fail_word8(q8, ah_d); }
+                FLG[cw] = flagged ? flag_word8(q8) : 0u;          // non-ACGT symbols (rare reads)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (l != F2Q_LEN_SKIP) {
-            const int r = (int)l;
+            const int r = (int)(l & 0x7FFFu);
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
             const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
             AnchorWin aw;
-            if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, LO, HI, r, FW, FW, FW);
-            else aw = anchor_window<NW, KB, KB>(run, LO, HI, r, FU, FD, FW);
+            if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, LO, HI, FLG, r, FW, FW, FW);
+            else aw = anchor_window<NW, KB, KB>(run, LO, HI, FLG, r, FU, FD, FW);
             const int L = aw.end - aw.start;
             if (aw.ok == 0) { st[4]++; st[0]++; }
             else if (aw.ok == 1 && !EC && (L < 1 || L > F2Q_REG_MAXLEN)) {
@@ -414,6 +417,20 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st2);
 #pragma unroll
                 for (int k = 0; k < 5; k++) st[k] += st2[k];
+            } else if (flagged && plane_extract<NW>(FLG, aw.start, L) != 0u) {
+                // the window itself holds non-ACGT symbols
+                st[0]++;
+                const uint32_t forced = plane_extract<NW>(FLG, aw.start, L);
+                if (EC) {
+                    // unreachable: Extract+Count keys hold the symbol itself, so the packer never flags reads in EC runs
+                    st[3]++;
+                } else if (!do_near || __popc(forced) > run.miss) st[3]++;
+                else {
+                    const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
+                    MinTrack t; t.init(run.miss);
+                    lib_near(lib, key, L, spread32(forced), t);           // wide tables, in place (rare)
+                    if (t.cnt == 1) { count_hit(t.idx); st[2]++; } else st[3]++;
+                }
             } else {
                 const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
                 st[0]++;
@@ -623,7 +640,7 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
         if ((p & 31) == 0) fw = rnd(s.seed, i, F_FLANK0 + (p >> 5));
         uint8_t c = synth_base(s, r, p, fw);
         uint32_t code = base_code(c); if (code > 3u) code = 0;
-        qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | ((p == npos && !o.planar_nw) ? 0x80u : 0u)) << (8 * (p & 3));
+        qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * (p & 3));
         if ((p & 3) == 3 || p == R - 1) { qp[(uint64_t)(p >> 2) * F2Q_TILE] = qw; qw = 0; }
         if (o.planar_nw) {                       // anchored runs: bit-planes, 32 bases per word
             lw |= (code & 1u) << (p & 31); hw |= (code >> 1) << (p & 31);
@@ -872,7 +889,7 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     if (rc) return rc;
     rc = alloc_acc(c, n);
     if (rc) return rc;
-    c->plan.inband_n = c->plan.fast_fixed && c->ix.n_irregular == 0;
+    c->plan.inband_n = (c->plan.fast_fixed || c->plan.fast_anchor) && c->ix.n_irregular == 0;
     if (c->ix.n_irregular) c->plan.fast_anchor = false;      // irregular features need the byte-exact routine
     c->have_lib = true;
     return F2Q_OK;
@@ -1369,7 +1386,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
     const bool fast = c->plan.fast_fixed || planar;
     SynthOut o; memset(&o, 0, sizeof o);
     o.all_general = fast ? 0 : 1;
-    o.inband_n = (c->plan.inband_n && !planar) ? 1 : 0;
+    o.inband_n = c->plan.inband_n ? 1 : 0;
     o.planar_nw = planar ? (R <= 96 ? 3u : 5u) : 0u;
     const uint64_t n_tiles = (s->n_reads + F2Q_TILE - 1) / F2Q_TILE;
     const uint64_t n_slots = n_tiles * F2Q_TILE;

@@ -72,7 +72,7 @@ void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t 
     }
     build_index(e->ix, seqs, offs, n, e->run.miss, packed_len);
     bind_lib(e);
-    e->plan.inband_n = e->plan.fast_fixed && e->ix.n_irregular == 0;
+    e->plan.inband_n = (e->plan.fast_fixed || e->plan.fast_anchor) && e->ix.n_irregular == 0;
     if (e->ix.n_irregular) e->plan.fast_anchor = false;
 }
 
@@ -100,11 +100,19 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             const uint32_t *qp = pb.qual + (uint64_t)t * pb.wq * F2Q_TILE + lane;
             for (int w = 0; w < NW; w++) { LO[w] = bp[(uint64_t)w * F2Q_TILE]; HI[w] = bp[(uint64_t)(NW + w) * F2Q_TILE]; }
             for (int i = 0; i < NQW; i++) Q[i] = qp[(uint64_t)((uint32_t)i < pb.wq ? i : pb.wq - 1) * F2Q_TILE];
-            const int r = (int)l;
+            const int r = (int)(l & 0x7FFFu);
+            const bool flagged = (l & F2Q_LEN_FLAG) != 0;
             const unsigned long long gi = e->reads_seen + hp_index[(uint64_t)t * F2Q_TILE + lane];
-            uint32_t FW[NW], FU[NW], FD[NW];
-            fail_vectors3<NW, NQW>(Q, e->run.thr, e->run.thr_up, e->run.thr_down, FW, FU, FD);
-            const AnchorWin aw = anchor_window<NW, KB, KB>(e->run, LO, HI, r, FU, FD, FW);
+            uint32_t FW[NW], FU[NW], FD[NW], FLG[NW];
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+                for (int i = 0; i < 8; i++) q8[i] = Q[8 * cw + i];
+                FW[cw] = fail_word8(q8, phred_add_hi(e->run.thr));
+                FU[cw] = fail_word8(q8, phred_add_hi(e->run.thr_up));
+                FD[cw] = fail_word8(q8, phred_add_hi(e->run.thr_down));
+                FLG[cw] = flagged ? flag_word8(q8) : 0u;
+            }
+            const AnchorWin aw = anchor_window<NW, KB, KB>(e->run, LO, HI, FLG, r, FU, FD, FW);
             const int L = aw.end - aw.start;
             const bool ecm = e->run.mode == 1;
             if (aw.ok == 0) { acc.stats[4]++; acc.stats[0]++; }
@@ -127,8 +135,19 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                 for (int i = 0; i < r; i++) {
                     sq[i] = (uint8_t)"ACGT"[((LO[i >> 5] >> (i & 31)) & 1u) | (((HI[i >> 5] >> (i & 31)) & 1u) << 1)];
                     ql[i] = (uint8_t)((Q[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                    if (ql[i] & 0x80u) { sq[i] = (uint8_t)'N'; ql[i] &= 0x7Fu; }
                 }
                 general_read<const uint8_t *>(e->run, e->lib, e->ec, acc, sq, r, ql, r, gi, acc.stats);
+            } else if (flagged && plane_extract<NW>(FLG, aw.start, L) != 0u) {
+                acc.stats[0]++;
+                const uint32_t forced = plane_extract<NW>(FLG, aw.start, L);
+                if (ecm || e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss) acc.stats[3]++;
+                else {
+                    const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
+                    MinTrack tt; tt.init(e->run.miss);
+                    lib_near(e->lib, key, L, spread32(forced), tt);
+                    if (tt.cnt == 1) { acc.counts[tt.idx]++; acc.stats[2]++; } else acc.stats[3]++;
+                }
             } else {
                 const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
                 acc.stats[0]++;

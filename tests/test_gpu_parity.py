@@ -247,3 +247,26 @@ def test_ec_table_growth_across_blocks(P):
         counts, stats = c.read_counts()
         assert list(stats) == orc.stats()
         assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+
+
+@pytest.mark.parametrize("anchors", ["both", "up", "down"])
+def test_packed_anchor_with_odd_symbols_gpu(P, anchors):
+    guides = synth.make_library(120, 16, 31337)
+    spec = synth.Spec(seed=4, n_reads=20000, read_len=120, cassette=True, up=UP, down=DOWN, max_offset=70, p_sub=0.25)
+    fq = sprinkle_symbols(synth.make_fastq(spec, guides), 11, rate=0.01)
+    kw = dict(miss=2, length=16, miss_search_up=1, miss_search_down=1)
+    if anchors in ("both", "up"):
+        kw["upstream"] = UP
+    if anchors in ("both", "down"):
+        kw["downstream"] = DOWN
+    for mode in ("C", "EC"):
+        o = O.Oracle(features=[(str(i), s) for i, s in enumerate(guides)] if mode == "C" else None, mode=mode, **kw)
+        o.count_fastq(fq)
+        with P.Counter(features=guides if mode == "C" else None, mode=mode, **kw) as c:
+            c.count_block(fq)
+            counts, stats = c.read_counts()
+            assert list(stats) == o.stats()
+            if mode == "C":
+                assert list(counts) == o.counts()
+            else:
+                assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts()))
