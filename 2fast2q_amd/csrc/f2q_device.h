@@ -59,6 +59,7 @@ struct RunDev {
     int32_t anchors_packed;            // 1: up_codes/down_codes are valid
     int32_t pad_;
     uint64_t up_codes, down_codes;     // symbol j = (codes >> 2j) & 3  -- one scalar load, no per-symbol memory access
+    uint32_t up_pos[4], down_pos[4];   // per symbol c: bit j set iff anchor symbol j == c
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -876,31 +877,10 @@ F2Q_HD void anchor_step(const uint32_t (&P)[NW], int j, uint32_t (&cnt)[KB > 0 ?
     }
 }
 
-// positions p at which an s-symbol anchor (2-bit codes) sits within k mismatches; KB = counter bits
-// (0: exact search, 1: k <= 1, 3: k <= 7).  For each of the four symbols the "base differs from it"
-// plane is formed once, then shifted and counted for every anchor position holding that symbol, so
-// only one plane is live at a time.  All loops and branches are wave-uniform.
+// bit-sliced "count <= k" over the counters of one anchor
 template <int NW, int KB>
-F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW], uint64_t codes,
-                        int s, int k, uint32_t (&hit)[NW])
+F2Q_HD void anchor_compare(const uint32_t (&cnt)[KB > 0 ? KB : 1][NW], const uint32_t (&ovf)[NW], int k, uint32_t (&hit)[NW])
 {
-    uint32_t cnt[KB > 0 ? KB : 1][NW], ovf[NW];
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        ovf[w] = 0;
-#pragma unroll
-        for (int b = 0; b < (KB > 0 ? KB : 1); b++) cnt[b][w] = 0;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const uint32_t la = (c & 1) ? ~0u : 0u, ha = (c & 2) ? ~0u : 0u;
-        uint32_t P[NW];
-#pragma unroll
-        for (int w = 0; w < NW; w++) P[w] = (LO[w] ^ la) | (HI[w] ^ ha) | FLG[w];   // 1 = base is not symbol c (flagged: never)
-        for (int j = 0; j < s; j++)
-            if ((int)((codes >> (2 * j)) & 3ull) == c) anchor_step<NW, KB>(P, j, cnt, ovf);
-    }
-    // hit = count <= k (bit-sliced compare against the wave-uniform k) and no overflow
 #pragma unroll
     for (int w = 0; w < NW; w++) {
         uint32_t gt = 0, eq = ~0u;
@@ -911,6 +891,39 @@ F2Q_HD void anchor_hits(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], cons
         }
         hit[w] = ~gt & ~ovf[w];
     }
+}
+
+// Hit vectors of the upstream and/or downstream anchor in one pass: positions p at which the anchor sits
+// within k mismatches (KB counter bits: 0 exact, 1: k <= 1, 3: k <= 7).  For each of the four symbols the
+// "base differs from it" plane is formed once and then shifted and counted for every position of either
+// anchor that holds the symbol (run.up_pos / run.down_pos are per-symbol position masks), so one plane is
+// live at a time and the scalar loop runs once per anchor symbol.  All loops/branches are wave-uniform.
+template <int NW, int KBU, int KBD>
+F2Q_HD void anchor_hits2(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW],
+                         uint32_t (&hu)[NW], uint32_t (&hd)[NW])
+{
+    uint32_t cu[KBU > 0 ? KBU : 1][NW], ou[NW], cd[KBD > 0 ? KBD : 1][NW], od[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        ou[w] = 0; od[w] = 0;
+#pragma unroll
+        for (int b = 0; b < (KBU > 0 ? KBU : 1); b++) cu[b][w] = 0;
+#pragma unroll
+        for (int b = 0; b < (KBD > 0 ? KBD : 1); b++) cd[b][w] = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t la = (c & 1) ? ~0u : 0u, ha = (c & 2) ? ~0u : 0u;
+        uint32_t P[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) P[w] = (LO[w] ^ la) | (HI[w] ^ ha) | FLG[w];   // 1 = base is not symbol c (flagged: never)
+        if (run.has_up)
+            for (uint32_t m = run.up_pos[c]; m; m &= m - 1u) anchor_step<NW, KBU>(P, ctz32(m), cu, ou);
+        if (run.has_down)
+            for (uint32_t m = run.down_pos[c]; m; m &= m - 1u) anchor_step<NW, KBD>(P, ctz32(m), cd, od);
+    }
+    anchor_compare<NW, KBU>(cu, ou, run.msu, hu);
+    anchor_compare<NW, KBD>(cd, od, run.msd, hd);
 }
 
 // first set bit at a position in [from, to] (inclusive) or -1
@@ -1035,19 +1048,16 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
     AnchorWin out; out.ok = 0; out.start = 0; out.end = 0;
     const int su = run.up_len[0], sd = run.down_len[0];
     int start, end;
+    uint32_t hu[NW], hd[NW];
+    anchor_hits2<NW, KBU, KBD>(run, LO, HI, FLG, hu, hd);
     if (run.has_up && run.has_down) {
-        uint32_t hu[NW], hd[NW];
-        anchor_hits<NW, KBU>(LO, HI, FLG, run.up_codes, su, run.msu, hu);
         const int pu = first_hit<NW>(hu, 0, r - su);
         if (pu < 0) return out;
-        anchor_hits<NW, KBD>(LO, HI, FLG, run.down_codes, sd, run.msd, hd);
         const int pd = first_hit<NW>(hd, pu + su, r - sd);
         if (pd < 0) return out;
         if (any_fail_short<NW>(FU, pu, su) || any_fail_short<NW>(FD, pd, sd)) return out;
         start = pu + su; end = pd;
     } else if (run.has_up) {
-        uint32_t hu[NW];
-        anchor_hits<NW, KBU>(LO, HI, FLG, run.up_codes, su, run.msu, hu);
         const int pu = first_hit<NW>(hu, 0, r - su);
         if (pu < 0) return out;
         if (any_fail_short<NW>(FU, pu, su)) return out;
@@ -1055,8 +1065,6 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
         if (run.length < 0) { out.ok = 2; return out; }
         if (end > r) end = r;                                   // Python slice clipping (:354)
     } else {
-        uint32_t hd[NW];
-        anchor_hits<NW, KBD>(LO, HI, FLG, run.down_codes, sd, run.msd, hd);
         const int pd = first_hit<NW>(hd, 0, r - sd);
         if (pd < 0) return out;
         if (any_fail_short<NW>(FD, pd, sd)) return out;

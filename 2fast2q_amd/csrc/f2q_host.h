@@ -400,6 +400,7 @@ inline int fill_run(const f2q_params &p, RunDev &r, std::string &err)
             uint32_t c = base_code(side ? r.down[0][k] : r.up[0][k]);
             if (c > 3u) { r.anchors_packed = 0; break; }
             (side ? r.down_codes : r.up_codes) |= (uint64_t)c << (2 * k);
+            (side ? r.down_pos : r.up_pos)[c] |= 1u << k;
         }
     }
     return F2Q_OK;
