@@ -332,7 +332,8 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     constexpr int NQW = 8 * NW;
     extern __shared__ unsigned long long smem64[];
     unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_V2_QCAP);
+    uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_V2_QCAP) + (threadIdx.x >> 6) * F2Q_V2_QCAP;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_V2_QCAP) + F2Q_AN_WAVES * F2Q_V2_QCAP;
     __shared__ uint32_t q_tails[F2Q_AN_WAVES];
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
@@ -427,9 +428,14 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 } else if (!do_near || __popc(forced) > run.miss) st[3]++;
                 else {
                     const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
-                    MinTrack t; t.init(run.miss);
-                    lib_near(lib, key, L, spread32(forced), t);           // wide tables, in place (rare)
-                    if (t.cnt == 1) { count_hit(t.idx); st[2]++; } else st[3]++;
+                    if (L == pk_len) {                                         // queued with its forced-mismatch mask
+                        uint32_t at = atomicAdd(q_tail, 1u);
+                        queue[at % F2Q_V2_QCAP] = key; qforced[at % F2Q_V2_QCAP] = forced;
+                    } else {
+                        MinTrack t; t.init(run.miss);
+                        lib_near(lib, key, L, spread32(forced), t);       // wide tables, in place (rare)
+                        if (t.cnt == 1) { count_hit(t.idx); st[2]++; } else st[3]++;
+                    }
                 }
             } else {
                 const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                     const int e = packed_exact(lib, key);
                     if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
                     else if (!do_near) st[3]++;
-                    else { uint32_t at = atomicAdd(q_tail, 1u); queue[at % F2Q_V2_QCAP] = key; }
+                    else { uint32_t at = atomicAdd(q_tail, 1u); queue[at % F2Q_V2_QCAP] = key; qforced[at % F2Q_V2_QCAP] = 0u; }
                 } else {
                     // a window of another length than the packed tables index: wide tables, in place (rare)
                     const int e = lib_exact(lib, key, L);
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
             const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
             while (tail - q_head >= 64u) {
                 uint32_t idx = 0;
-                int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], 0u, &idx);
+                int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
                 if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
                 q_head += 64u;
             }
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
         const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
         if (lane < tail - q_head) {
             uint32_t idx = 0;
-            int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], 0u, &idx);
+            int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
             if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
         }
     }
@@ -1003,7 +1009,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         const bool ecm = c->prm.mode == 1;
         const bool lds = !ecm && c->lib_h.n_features <= F2Q_HIST_MAX;
         const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * 4u);
-        const size_t shmem = (size_t)F2Q_AN_WAVES * F2Q_V2_QCAP * 8 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
+        const size_t shmem = (size_t)F2Q_AN_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
         if (!ecm) {
             const size_t need = lds ? (size_t)grid * c->lib_h.n_features : 0;
             if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
