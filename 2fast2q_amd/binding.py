@@ -244,8 +244,10 @@ class Counter:
         """fastq_parser over a bytes-like FASTQ buffer; returns bytes consumed (and timing)."""
         mv = memoryview(data)
         n = mv.nbytes
-        if isinstance(data, (bytes, bytearray)):
-            buf = (C.c_char * n).from_buffer_copy(data) if isinstance(data, bytes) else (C.c_char * n).from_buffer(data)
+        if isinstance(data, bytes):
+            ptr = C.cast(C.c_char_p(data), C.c_void_p)          # the bytes object's own buffer, no copy
+        elif isinstance(data, bytearray):
+            buf = (C.c_char * n).from_buffer(data)
             ptr = C.cast(buf, C.c_void_p)
         else:
             arr = np.frombuffer(mv, dtype=np.uint8)
@@ -264,10 +266,9 @@ class Counter:
         return t.as_dict(), False
 
     def block_from_fastq(self, data):
-        n = len(data)
-        buf = (C.c_char * n).from_buffer_copy(data)
+        data = bytes(data)
         h = C.c_void_p()
-        self._check(self._L.f2q_block_from_fastq(self._h, C.cast(buf, C.c_void_p), n, C.byref(h)))
+        self._check(self._L.f2q_block_from_fastq(self._h, C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(h)))
         return Block(self, h)
 
     def synth_guides(self, guides):

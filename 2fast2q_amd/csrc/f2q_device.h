@@ -1083,4 +1083,106 @@ F2Q_HD uint64_t plane_key(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], in
     return spread32(plane_extract<NW>(LO, start, L)) | (spread32(plane_extract<NW>(HI, start, L)) << 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// packing: which reads the tile planes can carry, and how one read is laid into them.  Shared by the
+// host packer (f2q_host.h) and the device packer (k_pack in f2q_kernels.hip).
+// ---------------------------------------------------------------------------------------------
+#define F2Q_PACK_MAXLEN 512
+#define F2Q_ANCHOR_MAXLEN 160      // longest read the packed anchored kernel holds in registers (5 x 32 bases)
+
+struct PackPlan {
+    bool fast_fixed = false;       // fixed offset, one window, 0 <= length <= 31, Counter mode
+    int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
+    int from = 0;                  // ... and only [from, need) is ever looked at
+    bool inband_n = false;         // non-ACGT symbols travel as flag bits (all-ACGT library only)
+    bool fast_anchor = false;      // one --us/--ds pair with ACGT anchors: packed bit-plane path
+    int kb = 1;                    // counter bits of the anchor search (0: exact, 1: k <= 1, 3: k <= 7)
+};
+
+template <class P>
+struct RecT { P seq; P qual; uint32_t len, qlen; };
+
+// Can this read go through a packed fast path?  The planes cannot carry a quality line of another length or
+// quality bytes >= 128 (bit 7 is the flag bit and the Phred SWAR test relies on 7-bit bytes); non-ACGT symbols
+// only as flag bits (all-ACGT library); anchored runs no lower case (the anchor search is case-sensitive, :337).
+template <class P>
+F2Q_HD bool read_is_clean(const PackPlan &pl, const RecT<P> &r)
+{
+    if (pl.fast_anchor) {
+        if (r.qlen != r.len || r.len > F2Q_ANCHOR_MAXLEN) return false;
+        for (uint32_t j = 0; j < r.len; j++) {
+            if (r.qual[j] & 0x80) return false;
+            const uint8_t c = r.seq[j];
+            if (base_code(c) > 3u && (!pl.inband_n || c == 'a' || c == 'c' || c == 'g' || c == 't')) return false;
+        }
+        return true;
+    }
+    if (!pl.fast_fixed) return false;
+    if (r.qlen != r.len) return false;
+    const uint32_t b = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
+    for (uint32_t j = (uint32_t)pl.from; j < b; j++) {
+        if (base_code(up8(r.seq[j])) > 3u && !pl.inband_n) return false;     // the window is upper-cased (:354)
+        if (r.qual[j] & 0x80) return false;
+    }
+    return true;
+}
+
+// number of bases of the read that are stored
+template <class P>
+F2Q_HD uint32_t packed_len(const PackPlan &pl, const RecT<P> &r)
+{
+    return pl.fast_anchor ? r.len : (r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need);
+}
+
+// tile geometry for a block whose longest stored read is rmax_in
+F2Q_HD void tile_geometry(const PackPlan &pl, uint32_t rmax_in, uint32_t &rmax, uint32_t &planar_nw, uint32_t &wb, uint32_t &wq)
+{
+    rmax = rmax_in ? rmax_in : 1u;
+    if (pl.fast_anchor) { planar_nw = rmax <= 96u ? 3u : 5u; wb = 2u * planar_nw; wq = 8u * planar_nw; }
+    else { planar_nw = 0; wb = (rmax + 15u) / 16u; wq = (rmax + 3u) / 4u; }
+}
+
+// one clean read -> its words (sink.base(w, v), sink.qual(w, v), sink.len(v))
+template <class P, class Sink>
+F2Q_HD void pack_read(const PackPlan &pl, const RecT<P> &r, uint32_t planar_nw, Sink &sink)
+{
+    const uint32_t l = packed_len(pl, r);
+    const uint32_t from = pl.fast_anchor ? 0u : (uint32_t)pl.from;
+    bool flagged = false;
+    if (planar_nw) {
+        for (uint32_t w = 0; w * 32 < l; w++) {
+            uint32_t lo = 0, hi = 0;
+            for (uint32_t j = 0; j < 32 && w * 32 + j < l; j++) {
+                uint32_t c = base_code(r.seq[w * 32 + j]);
+                if (c > 3u) { c = 0; flagged = true; }
+                lo |= (c & 1u) << j; hi |= ((c >> 1) & 1u) << j;
+            }
+            sink.base(w, lo); sink.base(planar_nw + w, hi);
+        }
+    } else {
+        for (uint32_t w = 0; w * 16 < l; w++) {
+            uint32_t v = 0;
+            for (uint32_t j = 0; j < 16 && w * 16 + j < l; j++) {
+                uint32_t c = base_code(up8(r.seq[w * 16 + j]));     // non-ACGT: stored as 'A'; inside the window it is
+                if (c > 3u) { c = 0; flagged |= (w * 16 + j >= from); }   // flagged, outside it is never looked at
+                v |= c << (2 * j);
+            }
+            sink.base(w, v);
+        }
+    }
+    for (uint32_t w = 0; w * 4 < l; w++) {
+        uint32_t v = 0;
+        for (uint32_t j = 0; j < 4 && w * 4 + j < l; j++) {
+            const uint32_t pos = w * 4 + j;
+            uint32_t q = r.qual[pos];
+            q = (q & 0x80u) ? 0u : q;                               // keep every stored byte 7-bit (SWAR)
+            const uint8_t sc = planar_nw ? (uint8_t)r.seq[pos] : up8(r.seq[pos]);
+            if (pos >= from && base_code(sc) > 3u) q |= 0x80u;      // flag bit
+            v |= q << (8 * j);
+        }
+        sink.qual(w, v);
+    }
+    sink.len(l | (flagged ? F2Q_LEN_FLAG : 0u));
+}
+
 } // namespace f2q

@@ -156,7 +156,7 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
 // ---------------------------------------------------------------------------------------------
 // FASTQ framing (fastq_parser :324-328): '\n'-separated lines, rstrip(), 4 lines per record
 // ---------------------------------------------------------------------------------------------
-struct Rec { const uint8_t *seq; const uint8_t *qual; uint32_t len, qlen; };
+typedef RecT<const uint8_t *> Rec;
 
 inline uint32_t rstrip_len(const uint8_t *p, size_t n)
 {
@@ -183,20 +183,8 @@ inline size_t frame_fastq(const uint8_t *buf, size_t nbytes, std::vector<Rec> &o
 }
 
 // ---------------------------------------------------------------------------------------------
-// packing plan
+// packing plan (PackPlan, read_is_clean, pack_read live in f2q_device.h: the device packer shares them)
 // ---------------------------------------------------------------------------------------------
-#define F2Q_PACK_MAXLEN 512
-
-struct PackPlan {
-    bool fast_fixed = false;       // fixed offset, one window, 0 <= length <= 31, Counter mode
-    int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
-    int from = 0;                  // ... and only [from, need) is ever looked at
-    bool inband_n = false;         // non-ACGT window symbols travel as flag bits (all-ACGT library only)
-    bool fast_anchor = false;      // one --us/--ds pair with ACGT anchors: packed bit-plane path
-    int kb = 1;                    // counter bits of the anchor search (0: exact, 1: k <= 1, 3: k <= 7)
-};
-#define F2Q_ANCHOR_MAXLEN 160      // longest read the packed anchored kernel holds in registers (5 x 32 bases)
-
 inline PackPlan make_plan(const RunDev &run)
 {
     PackPlan pl;
@@ -208,35 +196,6 @@ inline PackPlan make_plan(const RunDev &run)
                      run.msu <= 7 && run.msd <= 7 && run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN;
     pl.kb = (run.msu == 0 && run.msd == 0) ? 0 : (run.msu <= 1 && run.msd <= 1) ? 1 : 3;
     return pl;
-}
-
-// Can this read go through the packed fast path?  The 2-bit planes cannot carry lower case,
-// N/IUPAC symbols, a quality line of another length or quality bytes >= 128 (the Phred SWAR test
-// relies on 7-bit bytes); such reads take the general path, which works on the raw bytes.
-inline bool read_is_clean(const PackPlan &pl, const Rec &r)
-{
-    if (pl.fast_anchor) {
-        // the anchor search is case-sensitive on the raw read (:337), so only upper-case ACGT reads are packed
-        if (r.qlen != r.len || r.len > F2Q_ANCHOR_MAXLEN) return false;
-        for (uint32_t j = 0; j < r.len; j++) {
-            if (r.qual[j] & 0x80) return false;
-            if (base_code(r.seq[j]) > 3u) {
-                // symbols that equal no anchor/feature symbol travel as flag bits; lower-case acgt cannot (they
-                // differ from the anchors but match features after upper-casing, :337 vs :354)
-                const uint8_t c = r.seq[j];
-                if (!pl.inband_n || c == 'a' || c == 'c' || c == 'g' || c == 't') return false;
-            }
-        }
-        return true;
-    }
-    if (!pl.fast_fixed) return false;
-    if (r.qlen != r.len) return false;
-    uint32_t b = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
-    for (uint32_t j = (uint32_t)pl.from; j < b; j++) {
-        if (base_code(up8(r.seq[j])) > 3u && !pl.inband_n) return false;     // the window is upper-cased (:354)
-        if (r.qual[j] & 0x80) return false;
-    }
-    return true;
 }
 
 struct HostPacked {
@@ -252,6 +211,13 @@ struct HostPacked {
     std::vector<uint32_t> g_len, g_qlen, g_index;
 };
 
+struct HostSink {
+    uint32_t *bp, *qp; uint16_t *lp;
+    void base(uint32_t w, uint32_t v) { bp[(size_t)w * F2Q_TILE] = v; }
+    void qual(uint32_t w, uint32_t v) { qp[(size_t)w * F2Q_TILE] = v; }
+    void len(uint32_t v) { *lp = (uint16_t)v; }
+};
+
 inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostPacked &hp)
 {
     hp = HostPacked();
@@ -261,7 +227,7 @@ inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostP
         const Rec &r = recs[i];
         if (read_is_clean(pl, r)) {
             clean.push_back(i);
-            uint32_t l = pl.fast_anchor ? r.len : (r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need);
+            uint32_t l = packed_len(pl, r);
             if (l > rmax) rmax = l;
         } else {
             hp.g_off.push_back(hp.raw.size());
@@ -275,74 +241,16 @@ inline void pack_records(const PackPlan &pl, const std::vector<Rec> &recs, HostP
     if (clean.empty()) return;
     hp.c_index.assign(((clean.size() + F2Q_TILE - 1) / F2Q_TILE) * F2Q_TILE, 0);
     for (size_t s = 0; s < clean.size(); s++) hp.c_index[s] = clean[s];
-    if (rmax == 0) rmax = 1;
-    if (pl.fast_anchor) {
-        // planar layout; the kernel is instantiated for 3 or 5 words per plane
-        const uint32_t nw = rmax <= 96 ? 3u : 5u;
-        hp.planar_nw = nw; hp.rmax = rmax; hp.wb = 2 * nw; hp.wq = 8 * nw;
-        hp.n_tiles = (uint32_t)((clean.size() + F2Q_TILE - 1) / F2Q_TILE);
-        hp.bases.assign((size_t)hp.n_tiles * hp.wb * F2Q_TILE, 0);
-        hp.qual.assign((size_t)hp.n_tiles * hp.wq * F2Q_TILE, 0);
-        hp.len.assign((size_t)hp.n_tiles * F2Q_TILE, (uint16_t)F2Q_LEN_SKIP);
-        for (size_t s = 0; s < clean.size(); s++) {
-            const Rec &r = recs[clean[s]];
-            const size_t tile = s / F2Q_TILE, lane = s % F2Q_TILE;
-            bool flagged = false;
-            for (uint32_t j = 0; j < r.len; j++) flagged |= base_code(r.seq[j]) > 3u;
-            hp.len[tile * F2Q_TILE + lane] = (uint16_t)(r.len | (flagged ? F2Q_LEN_FLAG : 0u));
-            uint32_t *bp = hp.bases.data() + tile * hp.wb * F2Q_TILE + lane;
-            uint32_t *qp = hp.qual.data() + tile * hp.wq * F2Q_TILE + lane;
-            for (uint32_t w = 0; w * 32 < r.len; w++) {
-                uint32_t lo = 0, hi = 0;
-                for (uint32_t j = 0; j < 32 && w * 32 + j < r.len; j++) {
-                    uint32_t c = base_code(r.seq[w * 32 + j]);
-                    if (c > 3u) c = 0;
-                    lo |= (c & 1u) << j; hi |= ((c >> 1) & 1u) << j;
-                }
-                bp[(size_t)w * F2Q_TILE] = lo; bp[(size_t)(nw + w) * F2Q_TILE] = hi;
-            }
-            for (uint32_t w = 0; w * 4 < r.len; w++) {
-                uint32_t v = 0;
-                for (uint32_t j = 0; j < 4 && w * 4 + j < r.len; j++)
-                    v |= ((uint32_t)r.qual[w * 4 + j] | (base_code(r.seq[w * 4 + j]) > 3u ? 0x80u : 0u)) << (8 * j);
-                qp[(size_t)w * F2Q_TILE] = v;
-            }
-        }
-        return;
-    }
-    hp.rmax = rmax; hp.wb = (rmax + 15) / 16; hp.wq = (rmax + 3) / 4;
+    tile_geometry(pl, rmax, hp.rmax, hp.planar_nw, hp.wb, hp.wq);
     hp.n_tiles = (uint32_t)((clean.size() + F2Q_TILE - 1) / F2Q_TILE);
     hp.bases.assign((size_t)hp.n_tiles * hp.wb * F2Q_TILE, 0);
     hp.qual.assign((size_t)hp.n_tiles * hp.wq * F2Q_TILE, 0);
     hp.len.assign((size_t)hp.n_tiles * F2Q_TILE, (uint16_t)F2Q_LEN_SKIP);
     for (size_t s = 0; s < clean.size(); s++) {
-        const Rec &r = recs[clean[s]];
         const size_t tile = s / F2Q_TILE, lane = s % F2Q_TILE;
-        const uint32_t l = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
-        bool flagged = false;
-        for (uint32_t j = (uint32_t)pl.from; j < l; j++) flagged |= base_code(up8(r.seq[j])) > 3u;
-        hp.len[tile * F2Q_TILE + lane] = (uint16_t)(l | (flagged ? F2Q_LEN_FLAG : 0u));
-        uint32_t *bp = hp.bases.data() + tile * hp.wb * F2Q_TILE + lane;
-        uint32_t *qp = hp.qual.data() + tile * hp.wq * F2Q_TILE + lane;
-        for (uint32_t w = 0; w * 16 < l; w++) {
-            uint32_t v = 0;
-            for (uint32_t j = 0; j < 16 && w * 16 + j < l; j++) {
-                uint32_t c = base_code(up8(r.seq[w * 16 + j]));     // non-ACGT: stored as 'A'; inside the window it is
-                v |= (c > 3u ? 0u : c) << (2 * j);                  // flagged below, outside it is never looked at
-            }
-            bp[(size_t)w * F2Q_TILE] = v;
-        }
-        for (uint32_t w = 0; w * 4 < l; w++) {
-            uint32_t v = 0;
-            for (uint32_t j = 0; j < 4 && w * 4 + j < l; j++) {
-                const uint32_t pos = w * 4 + j;
-                uint32_t q = r.qual[pos];
-                q = (q & 0x80u) ? 0u : q;                           // keep every stored byte 7-bit (SWAR)
-                if (pos >= (uint32_t)pl.from && base_code(up8(r.seq[pos])) > 3u) q |= 0x80u;   // flag bit
-                v |= q << (8 * j);
-            }
-            qp[(size_t)w * F2Q_TILE] = v;
-        }
+        HostSink sink{hp.bases.data() + tile * hp.wb * F2Q_TILE + lane, hp.qual.data() + tile * hp.wq * F2Q_TILE + lane,
+                      hp.len.data() + tile * F2Q_TILE + lane};
+        pack_read(pl, recs[clean[s]], hp.planar_nw, sink);
     }
 }
 

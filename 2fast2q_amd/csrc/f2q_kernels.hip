@@ -11,6 +11,7 @@
 //   k_synth_*       device-side generator of the SURVEY §8(d) workload (bench input).
 //   k_ec_rehash     grows the Extract+Count table.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -529,8 +530,9 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const uint32_t *__restrict
 struct RawBlock {
     uint64_t n;
     uint64_t first_index;                  // global index of the block's read 0
-    const uint8_t *raw;                    // per record: seq bytes then quality bytes
-    const unsigned long long *off;
+    const uint8_t *raw;                    // record bytes (host packer: seq then quality; device packer: the FASTQ text itself)
+    const unsigned long long *off;         // offset of the sequence line
+    const unsigned long long *qoff;        // offset of the quality line, or nullptr: it follows the sequence
     const uint32_t *len, *qlen, *index;    // index: position inside the block (nullptr: == record id)
 };
 
@@ -545,8 +547,9 @@ __global__ __launch_bounds__(256) void k_count_general(const RunDev *__restrict_
          i += (uint64_t)gridDim.x * blockDim.x) {
         gbytes seq = gp(rb.raw) + gp(rb.off)[i];
         const int r = (int)gp(rb.len)[i], qn = (int)gp(rb.qlen)[i];
+        gbytes qual = rb.qoff ? gp(rb.raw) + gp(rb.qoff)[i] : seq + r;
         const unsigned long long gi = rb.first_index + (rb.index ? gp(rb.index)[i] : i);
-        general_read(run, lib, ec, acc, seq, r, seq + r, qn, gi, st);
+        general_read(run, lib, ec, acc, seq, r, qual, qn, gi, st);
     }
     __shared__ unsigned long long st_lds[8];
     flush_stats(acc, st, st_lds, nullptr);
@@ -661,6 +664,117 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
     }
 }
 
+// ---- device-side ingest: FASTQ text -> record table -> tiles ------------------------------------------
+// The host only moves the text to the device.  k_nl_count / k_line_starts find every line start (two passes
+// around a device-wide prefix sum), k_classify applies fastq_parser's framing (4 rstrip()-ed lines per record,
+// fast2q.py:324-328) and decides per read whether the tile planes can carry it, k_pack lays clean reads
+// into tiles and lists the others as raw records that point into the text itself.
+#define F2Q_NL_CHUNK 4096u          // bytes per workgroup: 256 threads x 16 bytes
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t F2Q_GLOBAL *text, uint64_t pos, uint64_t nbytes)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    v4 v = *(const v4 F2Q_GLOBAL *)(text + pos);                  // the buffer is padded to a chunk multiple
+    uint32_t m = 0;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (((w[k] >> (8 * b)) & 0xFFu) == (uint32_t)'\n' && pos + (uint64_t)(4 * k + b) < nbytes) m |= 1u << (4 * k + b);
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t *text, uint64_t nbytes, uint32_t *chunk_counts)
+{
+    typedef hipcub::BlockReduce<uint32_t, 256> BR;
+    __shared__ typename BR::TempStorage tmp;
+    const uint64_t pos = (uint64_t)blockIdx.x * F2Q_NL_CHUNK + threadIdx.x * 16u;
+    const uint32_t c = __popc(nl_mask16(gp(text), pos, nbytes));
+    const uint32_t tot = BR(tmp).Sum(c);
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = tot;
+}
+
+// line_start[k] = offset of line k; line_start[n_newlines + 1] = nbytes + 1 (end sentinel for an unterminated last line)
+__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint64_t nbytes, const uint32_t *chunk_prefix,
+                                                      uint32_t *line_start)
+{
+    typedef hipcub::BlockScan<uint32_t, 256> BS;
+    __shared__ typename BS::TempStorage tmp;
+    const uint64_t pos = (uint64_t)blockIdx.x * F2Q_NL_CHUNK + threadIdx.x * 16u;
+    uint32_t m = nl_mask16(gp(text), pos, nbytes);
+    uint32_t before = 0;
+    BS(tmp).ExclusiveSum((uint32_t)__popc(m), before);
+    uint32_t k = chunk_prefix[blockIdx.x] + before + 1u;
+    while (m) { const uint32_t b = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u; gpw(line_start)[k++] = (uint32_t)(pos + b + 1u); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) gpw(line_start)[0] = 0u;
+}
+
+struct IngestDev {
+    const uint8_t *text; const uint32_t *line_start; uint32_t n_records;
+    uint32_t *r_off, *r_len, *r_qoff, *r_qlen;   // per record: sequence / quality line (offset, rstrip()-ed length)
+    uint32_t *clean;                             // per record: 1 = goes into the tiles
+    uint32_t *meta;                              // [0] longest packed length among clean reads
+};
+
+__device__ __forceinline__ uint32_t rstrip_dev(gbytes p, uint32_t n)
+{
+    while (n > 0) {
+        const uint8_t c = p[n - 1];
+        if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c) n--; else break;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_classify(IngestDev d, PackPlan pl)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= d.n_records) return;
+    const auto ls = gp(d.line_start);
+    const uint32_t s0 = ls[4u * r + 1u], e0 = ls[4u * r + 2u] - 1u, s1 = ls[4u * r + 3u], e1 = ls[4u * r + 4u] - 1u;
+    RecT<gbytes> rec;
+    rec.seq = gp(d.text) + s0; rec.qual = gp(d.text) + s1;
+    rec.len = rstrip_dev(rec.seq, e0 - s0); rec.qlen = rstrip_dev(rec.qual, e1 - s1);
+    gpw(d.r_off)[r] = s0; gpw(d.r_len)[r] = rec.len; gpw(d.r_qoff)[r] = s1; gpw(d.r_qlen)[r] = rec.qlen;
+    const bool clean = read_is_clean(pl, rec);
+    gpw(d.clean)[r] = clean ? 1u : 0u;
+    if (clean) atomicMax(&d.meta[0], packed_len(pl, rec));
+}
+
+struct DevSink {
+    uint32_t F2Q_GLOBAL *bp; uint32_t F2Q_GLOBAL *qp; uint16_t F2Q_GLOBAL *lp;
+    __device__ void base(uint32_t w, uint32_t v) { bp[(uint64_t)w * F2Q_TILE] = v; }
+    __device__ void qual(uint32_t w, uint32_t v) { qp[(uint64_t)w * F2Q_TILE] = v; }
+    __device__ void len(uint32_t v) { *lp = (uint16_t)v; }
+};
+
+struct PackOut {
+    uint32_t *bases, *qual; uint16_t *len; uint32_t *c_index; uint32_t wb, wq, planar_nw;
+    unsigned long long *g_off, *g_qoff; uint32_t *g_len, *g_qlen, *g_index;
+};
+
+// clean_before = exclusive prefix sum of IngestDev::clean
+__global__ __launch_bounds__(256) void k_pack(IngestDev d, PackPlan pl, const uint32_t *clean_before, PackOut o)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= d.n_records) return;
+    const uint32_t slot = gp(clean_before)[r];
+    RecT<gbytes> rec;
+    rec.seq = gp(d.text) + gp(d.r_off)[r]; rec.qual = gp(d.text) + gp(d.r_qoff)[r];
+    rec.len = gp(d.r_len)[r]; rec.qlen = gp(d.r_qlen)[r];
+    if (gp(d.clean)[r]) {
+        const uint64_t tile = slot / F2Q_TILE, lane = slot % F2Q_TILE;
+        DevSink sink{gpw(o.bases) + tile * o.wb * F2Q_TILE + lane, gpw(o.qual) + tile * o.wq * F2Q_TILE + lane,
+                     gpw(o.len) + tile * F2Q_TILE + lane};
+        pack_read(pl, rec, o.planar_nw, sink);
+        if (o.c_index) gpw(o.c_index)[slot] = r;
+    } else {
+        const uint32_t g = r - slot;
+        gpw(o.g_off)[g] = gp(d.r_off)[r]; gpw(o.g_qoff)[g] = gp(d.r_qoff)[r];
+        gpw(o.g_len)[g] = rec.len; gpw(o.g_qlen)[g] = rec.qlen; gpw(o.g_index)[g] = r;
+    }
+}
+
 // ===============================================================================================
 // host side
 // ===============================================================================================
@@ -708,6 +822,7 @@ struct f2q_ctx {
     uint64_t reads_seen = 0;             // global read index of the next block's read 0
     int n_cu = 256;
     bool force_generic = false;           // F2Q_GENERIC=1: run-time window geometry even where a specialisation exists
+    bool host_pack = false;               // F2Q_HOST_PACK=1: frame/classify/pack on the host (the round-1 first path; A/B runs)
     bool force_v1 = false;                // F2Q_FORCE_V1=1: keep the one-read-per-lane kernel (A/B runs)
     std::string err;
 };
@@ -828,6 +943,7 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     c->device = p->device;
     { const char *fv = getenv("F2Q_FORCE_V1"); c->force_v1 = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_HOST_PACK"); c->host_pack = fv && fv[0] == '1'; }
     int rc = setup_run(c);
     if (rc) { g_create_err = c->err; delete c; return rc; }
 #define CREATE_HIP(call)                                                                            \
@@ -1194,10 +1310,112 @@ static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_bloc
     return F2Q_OK;
 }
 
+
+// FASTQ text -> resident block, framing and packing done by the device (k_nl_count .. k_pack).  Handles up to
+// 2 GiB of text per call; *consumed = bytes up to the end of the last complete record.
+static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_block **out)
+{
+    *out = nullptr; *consumed = 0;
+    f2q_block *b = new f2q_block();
+    std::vector<void *> tmp;                         // scratch freed before returning
+    int rc = F2Q_OK;
+    auto bail = [&](int code) { free_all(tmp); free_all(b->allocs); delete b; return code; };
+    const uint32_t n_chunks = (uint32_t)((nbytes + F2Q_NL_CHUNK - 1) / F2Q_NL_CHUNK);
+    const size_t padded = (size_t)n_chunks * F2Q_NL_CHUNK + 16;
+    uint8_t *d_text; uint32_t *d_cc, *d_cp;
+    if ((rc = dev_alloc(c, padded, &d_text, b->allocs))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)n_chunks + 1, &d_cc, tmp, 0))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)n_chunks + 1, &d_cp, tmp))) return bail(rc);
+#define ING(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, F2Q_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); return bail(F2Q_EHIP); } } while (0)
+    ING(hipMemsetAsync(d_text + nbytes, 0, padded - nbytes, c->stream));
+    ING(hipMemcpyAsync(d_text, fastq, nbytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_nl_count, dim3(n_chunks), dim3(256), 0, c->stream, d_text, (uint64_t)nbytes, d_cc);
+    ING(hipGetLastError());
+    size_t cub_bytes = 0;
+    ING(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, d_cc, d_cp, (int)n_chunks + 1, c->stream));
+    uint8_t *d_cub;
+    if ((rc = dev_alloc(c, cub_bytes + 16, &d_cub, tmp))) return bail(rc);
+    ING(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_cc, d_cp, (int)n_chunks + 1, c->stream));
+    uint32_t n_newlines = 0;
+    ING(hipMemcpyAsync(&n_newlines, d_cp + n_chunks, 4, hipMemcpyDeviceToHost, c->stream));
+    ING(hipStreamSynchronize(c->stream));
+    const bool open_tail = nbytes > 0 && fastq[nbytes - 1] != '\n';
+    const uint64_t n_lines = (uint64_t)n_newlines + (open_tail ? 1 : 0);
+    const uint32_t n_rec = (uint32_t)(n_lines / 4);
+    uint32_t *d_ls;
+    if ((rc = dev_alloc(c, (size_t)n_newlines + 2, &d_ls, tmp))) return bail(rc);
+    hipLaunchKernelGGL(k_line_starts, dim3(n_chunks), dim3(256), 0, c->stream, d_text, (uint64_t)nbytes, d_cp, d_ls);
+    ING(hipGetLastError());
+    const uint32_t sentinel = (uint32_t)nbytes + 1u;
+    ING(hipMemcpyAsync(d_ls + n_newlines + 1, &sentinel, 4, hipMemcpyHostToDevice, c->stream));
+    b->n_reads = n_rec;
+    if (n_rec == 0) { ING(hipStreamSynchronize(c->stream)); free_all(tmp); *out = b; return F2Q_OK; }
+    // bytes consumed: the start of line 4*n_rec, or everything when the last record's last line is unterminated
+    uint32_t cons32 = (uint32_t)nbytes;
+    if ((uint64_t)4 * n_rec <= n_newlines) ING(hipMemcpyAsync(&cons32, d_ls + (size_t)4 * n_rec, 4, hipMemcpyDeviceToHost, c->stream));
+    IngestDev ing{};
+    ing.text = d_text; ing.line_start = d_ls; ing.n_records = n_rec;
+    uint32_t *d_before;
+    if ((rc = dev_alloc(c, (size_t)n_rec, &ing.r_off, tmp))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)n_rec, &ing.r_len, tmp))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)n_rec, &ing.r_qoff, tmp))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)n_rec, &ing.r_qlen, tmp))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)n_rec + 1, &ing.clean, tmp, 0))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)n_rec + 1, &d_before, tmp))) return bail(rc);
+    if ((rc = dev_alloc(c, (size_t)4, &ing.meta, tmp, 0))) return bail(rc);
+    const unsigned rgrid = (n_rec + 255u) / 256u;
+    hipLaunchKernelGGL(k_classify, dim3(rgrid), dim3(256), 0, c->stream, ing, c->plan);
+    ING(hipGetLastError());
+    size_t cub2 = 0;
+    ING(hipcub::DeviceScan::ExclusiveSum(nullptr, cub2, ing.clean, d_before, (int)n_rec + 1, c->stream));
+    uint8_t *d_cub2;
+    if ((rc = dev_alloc(c, cub2 + 16, &d_cub2, tmp))) return bail(rc);
+    ING(hipcub::DeviceScan::ExclusiveSum(d_cub2, cub2, ing.clean, d_before, (int)n_rec + 1, c->stream));
+    uint32_t n_clean = 0, rmax_in = 0;
+    ING(hipMemcpyAsync(&n_clean, d_before + n_rec, 4, hipMemcpyDeviceToHost, c->stream));
+    ING(hipMemcpyAsync(&rmax_in, ing.meta, 4, hipMemcpyDeviceToHost, c->stream));
+    ING(hipStreamSynchronize(c->stream));
+    *consumed = cons32;
+    const uint32_t n_dirty = n_rec - n_clean;
+    PackOut o{};
+    if (n_clean) {
+        uint32_t rmax, nw, wb, wq;
+        tile_geometry(c->plan, rmax_in, rmax, nw, wb, wq);
+        const uint32_t n_tiles = (n_clean + F2Q_TILE - 1) / F2Q_TILE;
+        if ((rc = dev_alloc(c, (size_t)n_tiles * wb * F2Q_TILE, &o.bases, b->allocs, 0))) return bail(rc);
+        if ((rc = dev_alloc(c, (size_t)n_tiles * wq * F2Q_TILE, &o.qual, b->allocs, 0))) return bail(rc);
+        if ((rc = dev_alloc(c, (size_t)n_tiles * F2Q_TILE, &o.len, b->allocs, 0xFF))) return bail(rc);
+        if (c->prm.mode == 1 && (rc = dev_alloc(c, (size_t)n_tiles * F2Q_TILE, &o.c_index, b->allocs, 0))) return bail(rc);
+        o.wb = wb; o.wq = wq; o.planar_nw = nw;
+        b->pb.n_slots = (uint64_t)n_tiles * F2Q_TILE; b->pb.n_tiles = n_tiles; b->pb.wb = wb; b->pb.wq = wq; b->pb.rmax = rmax;
+        b->pb.planar_nw = nw; b->pb.bases = o.bases; b->pb.qual = o.qual; b->pb.len = o.len; b->pb.index = o.c_index;
+        b->dev_bytes += (uint64_t)n_tiles * F2Q_TILE * ((wb + wq) * 4 + 2);
+    }
+    if (n_dirty) {
+        if ((rc = dev_alloc(c, (size_t)n_dirty, &o.g_off, b->allocs))) return bail(rc);
+        if ((rc = dev_alloc(c, (size_t)n_dirty, &o.g_qoff, b->allocs))) return bail(rc);
+        if ((rc = dev_alloc(c, (size_t)n_dirty, &o.g_len, b->allocs))) return bail(rc);
+        if ((rc = dev_alloc(c, (size_t)n_dirty, &o.g_qlen, b->allocs))) return bail(rc);
+        if ((rc = dev_alloc(c, (size_t)n_dirty, &o.g_index, b->allocs))) return bail(rc);
+        b->rb.n = n_dirty; b->rb.raw = d_text; b->rb.off = o.g_off; b->rb.qoff = o.g_qoff; b->rb.len = o.g_len;
+        b->rb.qlen = o.g_qlen; b->rb.index = o.g_index;
+        b->dev_bytes += nbytes;                       // upper bound of the key bytes an Extract+Count run can add
+    }
+    b->n_general = n_dirty;
+    hipLaunchKernelGGL(k_pack, dim3(rgrid), dim3(256), 0, c->stream, ing, c->plan, d_before, o);
+    ING(hipGetLastError());
+    ING(hipStreamSynchronize(c->stream));             // scratch dies with this frame
+#undef ING
+    free_all(tmp);
+    *out = b;
+    return F2Q_OK;
+}
+
 extern "C" int f2q_block_from_fastq(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, f2q_block **out)
 {
     if (!c || !out || (!fastq && nbytes)) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
+    if (!c->host_pack && nbytes < ((size_t)1 << 31)) { size_t used; return block_from_text_device(c, fastq, nbytes, &used, out); }
     std::vector<Rec> recs;
     frame_fastq(fastq, nbytes, recs);
     return block_from_records(c, recs, out);
@@ -1208,24 +1426,41 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
     if (!c || (!fastq && nbytes)) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
     if (t) { memset(t, 0, sizeof *t); HIPC(c, hipEventRecord(c->ev_a, c->stream)); }
-    std::vector<Rec> recs;
-    size_t used = frame_fastq(fastq, nbytes, recs);
-    if (consumed) *consumed = used;
-    if (recs.empty()) return F2Q_OK;
-    f2q_block *b = nullptr;
-    int rc = block_from_records(c, recs, &b);
-    if (rc) return rc;
-    rc = launch_block(c, b, t);
-    if (!rc && t) {
+    if (consumed) *consumed = 0;
+    int rc = F2Q_OK;
+    size_t pos = 0;
+    f2q_timing sum; memset(&sum, 0, sizeof sum);
+    while (pos < nbytes) {
+        // the device packer indexes the text with 32 bits: feed it at most 1 GiB at a time (record aligned by itself)
+        const size_t take = std::min<size_t>(nbytes - pos, (size_t)1 << 30);
+        f2q_block *b = nullptr; size_t used = 0;
+        if (!c->host_pack) rc = block_from_text_device(c, fastq + pos, take, &used, &b);
+        else {
+            std::vector<Rec> recs;
+            used = frame_fastq(fastq + pos, take, recs);
+            rc = recs.empty() ? F2Q_OK : block_from_records(c, recs, &b);
+        }
+        if (rc) return rc;
+        f2q_timing one; memset(&one, 0, sizeof one);
+        if (b && b->n_reads) rc = launch_block(c, b, t ? &one : nullptr);
+        if (b) f2q_block_free(c, b);
+        if (rc) return rc;
+        sum.kernel_ms += one.kernel_ms; sum.reads += one.reads; sum.fast_reads += one.fast_reads;
+        sum.general_reads += one.general_reads; sum.launches += one.launches;
+        if (used == 0) break;                          // no complete record left in this window
+        pos += used;
+        if (take < ((size_t)1 << 30)) break;           // that was the tail: what is left is a partial record
+    }
+    if (consumed) *consumed = pos;
+    if (t) {
         hipError_t e = hipEventRecord(c->ev_b, c->stream);
         if (e == hipSuccess) e = hipEventSynchronize(c->ev_b);
         float ms = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev_a, c->ev_b);
-        if (e != hipSuccess) rc = fail(c, F2Q_EHIP, hipGetErrorString(e));
-        t->total_ms = ms;
+        if (e != hipSuccess) return fail(c, F2Q_EHIP, hipGetErrorString(e));
+        *t = sum; t->total_ms = ms;
     }
-    f2q_block_free(c, b);
-    return rc;
+    return F2Q_OK;
 }
 
 // reads_counter's file half (fast2q.py:560-578): gzip or plain by extension; streamed in blocks
@@ -1234,16 +1469,44 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
     if (!c || !path) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
     const size_t CH = (size_t)256 << 20;
-    gzFile f = gzopen(path, "rb");               // zlib reads plain files transparently
-    if (!f) return fail(c, F2Q_EIO, std::string("cannot open ") + path);
-    gzbuffer(f, 1 << 20);
-    std::vector<uint8_t> buf(CH);
+    // gzip by content (1f 8b), like gzip.open() by extension upstream (:567); plain files are read() straight
+    // into the pinned buffer, without zlib's pass-through copy
+    FILE *pf = fopen(path, "rb");
+    if (!pf) return fail(c, F2Q_EIO, std::string("cannot open ") + path);
+    unsigned char magic[2] = {0, 0};
+    const size_t got_magic = fread(magic, 1, 2, pf);
+    const bool is_gz = got_magic == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    rewind(pf);
+    gzFile f = nullptr;
+    if (is_gz) {
+        fclose(pf); pf = nullptr;
+        f = gzopen(path, "rb");
+        if (!f) return fail(c, F2Q_EIO, std::string("cannot open ") + path);
+        gzbuffer(f, 1 << 20);
+    }
+    // page-locked staging buffer: the H2D copy of the text then runs at DMA speed
+    struct Pinned {
+        uint8_t *p = nullptr; size_t n = 0;
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+        uint8_t *data() { return p; }
+        size_t size() const { return n; }
+        bool resize(size_t m) {
+            uint8_t *q = nullptr;
+            if (hipHostMalloc((void **)&q, m, hipHostMallocDefault) != hipSuccess) return false;
+            if (p) { memcpy(q, p, n < m ? n : m); (void)hipHostFree(p); }
+            p = q; n = m; return true;
+        }
+    } buf;
+    if (!buf.resize(CH)) { if (f) gzclose(f); if (pf) fclose(pf); return fail(c, F2Q_ENOMEM, "cannot allocate the pinned read buffer"); }
     size_t have = 0;
     f2q_timing sum; memset(&sum, 0, sizeof sum);
     int rc = F2Q_OK; bool truncated = false;
     for (;;) {
-        int got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
-        if (got < 0) { truncated = true; got = 0; }
+        long got;
+        if (f) {
+            got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
+            if (got < 0) { truncated = true; got = 0; }
+        } else got = (long)fread(buf.data() + have, 1, buf.size() - have, pf);
         have += (size_t)got;
         const bool eof = (got == 0);
         if (have == 0) break;
@@ -1254,8 +1517,8 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
         } else {
             // only hand over whole lines: cut at the last newline so a line is never split between blocks
             size_t cut = have;
-            while (cut > 0 && buf[cut - 1] != '\n') cut--;
-            if (cut == 0) { if (have == buf.size()) buf.resize(buf.size() * 2); continue; }
+            while (cut > 0 && buf.data()[cut - 1] != 0x0a) cut--;
+            if (cut == 0) { if (have == buf.size() && !buf.resize(buf.size() * 2)) { rc = fail(c, F2Q_ENOMEM, "line longer than memory"); break; } continue; }
             rc = f2q_count_block(c, buf.data(), cut, &used, &one);
         }
         if (rc) break;
@@ -1264,11 +1527,14 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
         memmove(buf.data(), buf.data() + used, have - used);
         have -= used;
         if (eof) break;
-        if (have == buf.size()) buf.resize(buf.size() * 2);
+        if (have == buf.size() && !buf.resize(buf.size() * 2)) { rc = fail(c, F2Q_ENOMEM, "record longer than memory"); break; }
     }
-    int zerr = 0; (void)gzerror(f, &zerr);
-    if (zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) truncated = true;
-    gzclose(f);
+    if (f) {
+        int zerr = 0; (void)gzerror(f, &zerr);
+        if (zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) truncated = true;
+        gzclose(f);
+    }
+    if (pf) fclose(pf);
     if (t) *t = sum;
     if (rc) return rc;
     if (truncated) return fail(c, F2Q_ETRUNCATED, std::string(path) + " is an incomplete or corrupted gzip file");

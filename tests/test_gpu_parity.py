@@ -270,3 +270,33 @@ def test_packed_anchor_with_odd_symbols_gpu(P, anchors):
                 assert list(counts) == o.counts()
             else:
                 assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts()))
+
+
+@pytest.mark.parametrize("host_pack", ["0", "1"], ids=["device_packer", "host_packer"])
+def test_both_packers_agree_with_the_oracle(P, monkeypatch, host_pack):
+    """the device ingest (k_nl_count .. k_pack) and the host packer produce the same counts on awkward text:
+    CRLF, blank-line shift, unterminated last line, partial record, ragged lengths, odd symbols"""
+    monkeypatch.setenv("F2Q_HOST_PACK", host_pack)
+    guides = synth.make_library(100, 20, 5150)
+    body = synth.make_fastq(synth.Spec(seed=1, n_reads=3000, read_len=70), guides)
+    ragged = b"".join(synth.make_fastq(synth.Spec(seed=2 + k, n_reads=200, read_len=rl), guides) for k, rl in enumerate((19, 20, 21, 33, 64, 65)))
+    texts = {
+        "plain": body, "crlf": body.replace(b"\n", b"\r\n"), "no_final_newline": body[:-1],
+        "partial_record": body + b"@x\nACGT\n+\n", "blank_shift": b"\n" + body, "ragged": ragged,
+        "symbols": sprinkle_symbols(body, 3, rate=0.02), "trailing_ws": body.replace(b"I\n", b"I \t\n", 500),
+        "one_record": b"@r\n" + guides[0].encode() + b"\n+\n" + b"I" * 20 + b"\n", "empty": b"",
+    }
+    for name, fq in texts.items():
+        for kw in (dict(miss=1), dict(miss=1, upstream="ACGT", length=12), dict(mode="EC", start="3", length=17)):
+            feats = None if kw.get("mode") == "EC" else guides
+            o = O.Oracle(features=[(str(i), s) for i, s in enumerate(guides)] if feats else None, **kw)
+            used_o = o.count_fastq(fq)
+            with P.Counter(features=feats, **kw) as c:
+                used = c.count_block(fq)
+                counts, stats = c.read_counts()
+                assert used == used_o, (name, kw)
+                assert list(stats) == o.stats(), (name, kw)
+                if feats:
+                    assert list(counts) == o.counts(), (name, kw)
+                else:
+                    assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts())), (name, kw)
