@@ -491,7 +491,7 @@ F2Q_HD void ec_insert(const EcDev &ec, const KV &kv, unsigned long long read_ind
                 for (int w = 0; w < nw && same; w++) same = (F2Q_LD32(&ec.arena[off + w]) == key_word(kv, w));
                 if (same) {
                     ec_fetch_add(&ec.ent_count[e], 1ull);
-                    ec_min(&ec.ent_first[e], read_index);
+                    if (read_index < F2Q_LD64(&ec.ent_first[e])) ec_min(&ec.ent_first[e], read_index);
                     return;
                 }
             }
@@ -514,7 +514,8 @@ F2Q_HD void ec64_insert(const EcDev &ec, uint64_t key, int len, unsigned long lo
         }
         if (v == k) {
             ec_fetch_add(&ec.k64_count[s], 1ull);
-            ec_min(&ec.k64_first[s], read_index);
+            // the minimum only ever decreases: a plain look first saves the read-modify-write for almost every read
+            if (read_index < F2Q_LD64(&ec.k64_first[s])) ec_min(&ec.k64_first[s], read_index);
             return;
         }
         s = (s + 1) & ec.k64_mask;

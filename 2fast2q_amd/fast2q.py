@@ -12,7 +12,7 @@ What is different: reads_counter() does no per-read work in Python.  It hands th
 libf2q_hip.so (include/f2q.h) through ctypes; FASTQ framing, Phred masking, window / anchored
 extraction, <= m mismatch matching and count accumulation all run in the library (HIP kernels on
 gfx950).  The reference's Numba helpers, multiprocessing pools, memo caches and chunk splitter
-have no counterpart here (--cp / --fs are accepted and ignored).  There is no CPU fallback: without
+have no counterpart here (--cp = samples in flight, as threads; --fs is accepted and ignored).  There is no CPU fallback: without
 the library or a GPU, reads_counter raises.
 
 Multi-GPU: when launched with one process per GPU (torchrun; RANK/WORLD_SIZE set) every rank
@@ -346,10 +346,25 @@ def aligner_mp_dispenser(features, param, start=0):
     sharding.barrier()
     reads_stats = {"failed_reads": set(), "passed_reads": {}}
     colourful_errors("INFO", f"Processing {param['sequencing_files']['len_files']} files. Please hold.")
-    for i, raw in enumerate(param['sequencing_files']['files']):
+
+    def one(i, raw):
         # Counter mode: each sample starts from zeroed counts, as the per-process `features` copy does upstream
         per_sample = {k: Features(v.name, 0) for k, v in features.items()} if param['Running Mode'] == 'C' else {}
         aligner(i, raw, per_sample, param, reads_stats)
+
+    files = list(enumerate(param['sequencing_files']['files']))
+    workers = min(int(param.get("cpu") or 1), len(files), 16)
+    if workers > 1 and sharding.world().size == 1:
+        # --cp samples in flight, as upstream (:1646-1655) -- threads, not processes: the per-read work is in the
+        # library (ctypes drops the GIL), each sample has its own context and HIP stream, and for .gz input the
+        # single-threaded inflate of one file overlaps with the inflate and the GPU work of the others
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for fut in [pool.submit(one, i, raw) for i, raw in files]:
+                fut.result()
+    else:
+        for i, raw in files:
+            one(i, raw)
 
 
 def compiling(param):

@@ -106,3 +106,26 @@ def test_cli_directory_of_samples(tmp_path):
     assert [r[0] for r in rows[1:]] == [str(v) for v in sorted(100 - i for i in range(60))]
     for r in rows[1:]:
         assert int(r[1]) == exp["s1"][r[0]] and int(r[2]) == exp["s2"][r[0]]
+
+
+def test_cli_samples_in_parallel_threads(tmp_path):
+    """--cp N: N samples in flight (threads over independent contexts); results identical to one at a time"""
+    guides = synth.make_library(40, 20, 45)
+    (tmp_path / "in").mkdir()
+    csvp = tmp_path / "lib.csv"
+    csvp.write_text("".join(f"g{i},{g}\n" for i, g in enumerate(guides)))
+    exp = {}
+    for k in range(6):
+        fq = synth.make_fastq(synth.Spec(seed=60 + k, n_reads=800 + 100 * k, read_len=45), guides)
+        with gzip.open(tmp_path / "in" / f"s{k}.fastq.gz", "wb") as f:
+            f.write(fq)
+        orc = O.Oracle(features=[(f"g{i}", g) for i, g in enumerate(guides)], miss=1)
+        orc.count_fastq(fq)
+        exp[f"s{k}"] = dict(zip(orc.names, orc.counts()))
+    fast2q.main(["-c", "--s", str(tmp_path / "in"), "--g", str(csvp), "--o", str(tmp_path), "--pb", "--cp", "4"])
+    out = [d for d in tmp_path.iterdir() if d.is_dir() and d.name.startswith("2FAST2Q_output_")][0]
+    rows = list(csv.reader(open(out / "compiled.csv", newline="")))
+    assert rows[0] == ["#Feature"] + [f"s{k}" for k in range(6)]
+    for r in rows[1:]:
+        for k in range(6):
+            assert int(r[1 + k]) == exp[f"s{k}"][r[0]]
