@@ -1317,6 +1317,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
 {
     *out = nullptr; *consumed = 0;
     f2q_block *b = new f2q_block();
+    if (nbytes == 0) { *out = b; return F2Q_OK; }    // an empty buffer is an empty block
     std::vector<void *> tmp;                         // scratch freed before returning
     int rc = F2Q_OK;
     auto bail = [&](int code) { free_all(tmp); free_all(b->allocs); delete b; return code; };

@@ -300,3 +300,23 @@ def test_both_packers_agree_with_the_oracle(P, monkeypatch, host_pack):
                     assert list(counts) == o.counts(), (name, kw)
                 else:
                     assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts())), (name, kw)
+
+
+def test_resident_block_from_host_fastq(P):
+    """f2q_block_from_fastq keeps a host FASTQ resident in the tile layout; counting it repeatedly accumulates"""
+    guides = synth.make_library(500, 20, 8)
+    fq = synth.make_fastq(synth.Spec(seed=14, n_reads=20000, read_len=101), guides)
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(guides)], miss=2)
+    o.count_fastq(fq)
+    with P.Counter(features=guides, miss=2) as c:
+        blk = c.block_from_fastq(fq)
+        assert blk.info()["n_reads"] == 20000
+        for k in (1, 2, 3):
+            c.count_resident(blk)
+            counts, stats = c.read_counts()
+            assert list(stats) == [k * v for v in o.stats()] and list(counts) == [k * v for v in o.counts()]
+        blk.free()
+        empty = c.block_from_fastq(b"")
+        assert empty.info()["n_reads"] == 0
+        c.count_resident(empty)
+        empty.free()
