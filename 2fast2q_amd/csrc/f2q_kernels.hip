@@ -823,6 +823,7 @@ struct f2q_ctx {
     int n_cu = 256;
     bool force_generic = false;           // F2Q_GENERIC=1: run-time window geometry even where a specialisation exists
     bool host_pack = false;               // F2Q_HOST_PACK=1: frame/classify/pack on the host (the round-1 first path; A/B runs)
+    bool force_general = false;           // F2Q_FORCE_GENERAL=1: every read through the byte-exact general kernel (cross-checks)
     bool force_v1 = false;                // F2Q_FORCE_V1=1: keep the one-read-per-lane kernel (A/B runs)
     std::string err;
 };
@@ -885,6 +886,7 @@ static int setup_run(f2q_ctx *c)
     int rc = fill_run(p, c->run_h, err);
     if (rc) return fail(c, rc, err);
     c->plan = make_plan(c->run_h);
+    if (c->force_general) { c->plan.fast_fixed = false; c->plan.fast_anchor = false; }
     return F2Q_OK;
 }
 
@@ -944,6 +946,7 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     { const char *fv = getenv("F2Q_FORCE_V1"); c->force_v1 = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_HOST_PACK"); c->host_pack = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_FORCE_GENERAL"); c->force_general = fv && fv[0] == '1'; }
     int rc = setup_run(c);
     if (rc) { g_create_err = c->err; delete c; return rc; }
 #define CREATE_HIP(call)                                                                            \

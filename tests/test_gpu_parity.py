@@ -320,3 +320,59 @@ def test_resident_block_from_host_fastq(P):
         assert empty.info()["n_reads"] == 0
         c.count_resident(empty)
         empty.free()
+
+
+def _full(P, monkeypatch, env, lib, spec, **kw):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with P.Counter(features=lib if kw.get("mode", "C") == "C" else None, **kw) as c:
+        blk = c.synth_create(guides=lib, **spec)
+        t = c.count_resident(blk)
+        counts, stats = c.read_counts()
+        ec = c.ec_results() if kw.get("mode") == "EC" else None
+        blk.free()
+    for k in env:
+        monkeypatch.delenv(k)
+    return list(counts), list(stats), ec, t
+
+
+def test_full_size_config3_cross_paths(P, monkeypatch):
+    """BASELINE config 3 at full size (50M x 150 bp, 10k guides, --m 1): the 4-reads-per-lane kernel, the
+    one-read-per-lane kernel and the byte-exact general kernel (validated against the oracle at small sizes)
+    must agree bit for bit; plus the size-independent identities."""
+    lib = P.binding.synth_library(0xF2A5 + 3, 10000, 20)
+    spec = dict(seed=0xBEEF, n_reads=50_000_000, read_len=150)
+    kw = dict(miss=1, phred=30, length=20, start="0")
+    c2, s2, _, t2 = _full(P, monkeypatch, {}, lib, spec, **kw)
+    c1, s1, _, _ = _full(P, monkeypatch, {"F2Q_FORCE_V1": "1"}, lib, spec, **kw)
+    assert s2[0] == 50_000_000 and s2[0] == sum(s2[1:]) and sum(c2) == s2[1] + s2[2]
+    assert t2["general_reads"] == 0
+    assert (c1, s1) == (c2, s2)
+    spec_q = dict(spec, n_reads=12_500_000)                       # a quarter through the general kernel (byte-wise, slow)
+    cg, sg, _, tg = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, spec_q, **kw)
+    cq, sq, _, _ = _full(P, monkeypatch, {}, lib, spec_q, **kw)
+    assert tg["general_reads"] == 12_500_000 and (cg, sg) == (cq, sq)
+
+
+def test_full_size_config5_cross_paths(P, monkeypatch):
+    """BASELINE config 5 (anchored, Counter and Extract+Count) at 50M reads: invariants, and the packed
+    bit-plane kernel against the byte-exact general kernel on a 10M-read slice of the same stream."""
+    lib = P.binding.synth_library(0xF2A5 + 5, 10000, 20)
+    up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+    spec = dict(seed=0xBEEF, n_reads=50_000_000, read_len=150, cassette=True, up=up, down=down, max_offset=100)
+    kw = dict(miss=1, upstream=up, downstream=down, miss_search_up=1, miss_search_down=1)
+    c5, s5, _, t5 = _full(P, monkeypatch, {}, lib, spec, **kw)
+    assert s5[0] == 50_000_000 and s5[0] == sum(s5[1:]) and sum(c5) == s5[1] + s5[2] and t5["general_reads"] == 0
+    _, se, ec, _ = _full(P, monkeypatch, {}, lib, spec, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
+    assert se[0] == 50_000_000 and se[1] + se[4] == se[0] and sum(n for _, n, _ in ec) == se[1]
+    assert se[4] == s5[4]                                         # the same reads fail quality in both modes
+    by_key = {k: n for k, n, _ in ec}
+    # a read counted as a PERFECT hit of guide g in Counter mode is a read whose extracted key is g in EC mode
+    assert sum(by_key.get(g, 0) for g in lib) == s5[1]
+    sl = dict(spec, n_reads=10_000_000)
+    cp, sp, _, _ = _full(P, monkeypatch, {}, lib, sl, **kw)
+    cg, sg, _, tg = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, sl, **kw)
+    assert tg["general_reads"] == 10_000_000 and (cp, sp) == (cg, sg)
+    _, sp2, ecp, _ = _full(P, monkeypatch, {}, lib, sl, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
+    _, sg2, ecg, _ = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, sl, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
+    assert sp2 == sg2 and ecp == ecg
