@@ -965,23 +965,6 @@ F2Q_HD uint32_t plane_extract(const uint32_t (&P)[NW], int start, int L)
     return L >= 32 ? v : (v & ((1u << L) - 1u));
 }
 
-// per-base Phred fail vector from NQ quality words (4 bytes each, all < 128): bit i = byte i fails thr
-template <int NW, int NQW>
-F2Q_HD void fail_vector(const uint32_t (&Q)[NQW], int thr, uint32_t (&F)[NW])
-{
-#pragma unroll
-    for (int w = 0; w < NW; w++) F[w] = 0;
-    if (thr < 33) return;
-    const uint32_t add_lo = 0x5F5F5F5Fu, add_hi = (uint32_t)(127 - thr) * 0x01010101u;
-#pragma unroll
-    for (int i = 0; i < NQW; i++) {
-        if (i / 8 < NW) {
-            const uint32_t f = qfail4(Q[i], add_lo, add_hi, 0x80808080u) >> 7;      // 0/1 at bits 0, 8, 16, 24
-            F[i / 8] |= (((f * 0x00204081u) >> 21) & 0xFu) << (4 * (i % 8));
-        }
-    }
-}
-
 // Phred fail bits of 32 bases from their 8 quality words (bytes < 128); add_hi == 0: rule off
 F2Q_HD uint32_t fail_word8(const uint32_t (&q)[8], uint32_t add_hi)
 {
@@ -1001,32 +984,6 @@ F2Q_HD uint32_t flag_word8(const uint32_t (&q)[8])
     return f;
 }
 F2Q_HD uint32_t phred_add_hi(int thr) { return thr >= 33 ? (uint32_t)(127 - thr) * 0x01010101u : 0u; }
-
-// the three per-base fail vectors of an anchored run (--ph window, --qsu, --qsd) in ONE pass over the
-// quality words, so that each word is dead after its use; equal thresholds share the work
-template <int NW, int NQW>
-F2Q_HD void fail_vectors3(const uint32_t (&Q)[NQW], int thr, int thr_up, int thr_down,
-                          uint32_t (&FW)[NW], uint32_t (&FU)[NW], uint32_t (&FD)[NW])
-{
-    const bool su = thr_up == thr, sd = thr_down == thr;             // wave-uniform
-    const uint32_t add_lo = 0x5F5F5F5Fu;
-    const uint32_t hw = thr >= 33 ? (uint32_t)(127 - thr) * 0x01010101u : 0u;
-    const uint32_t hu = thr_up >= 33 ? (uint32_t)(127 - thr_up) * 0x01010101u : 0u;
-    const uint32_t hd = thr_down >= 33 ? (uint32_t)(127 - thr_down) * 0x01010101u : 0u;
-#pragma unroll
-    for (int w = 0; w < NW; w++) { FW[w] = 0; FU[w] = 0; FD[w] = 0; }
-#pragma unroll
-    for (int i = 0; i < NQW; i++) {
-        if (i / 8 < NW) {
-            const int sh = 4 * (i % 8);
-            if (hw) FW[i / 8] |= ((((qfail4(Q[i], add_lo, hw, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << sh;
-            if (!su && hu) FU[i / 8] |= ((((qfail4(Q[i], add_lo, hu, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << sh;
-            if (!sd && hd) FD[i / 8] |= ((((qfail4(Q[i], add_lo, hd, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << sh;
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < NW; w++) { if (su) FU[w] = FW[w]; if (sd) FD[w] = FW[w]; }
-}
 
 // result of the extraction stage of one packed read in an anchored run
 struct AnchorWin { int ok; int start, end; };      // ok: 0 = no window (counts as quality-failed, :345-347),
