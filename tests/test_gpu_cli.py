@@ -129,3 +129,35 @@ def test_cli_samples_in_parallel_threads(tmp_path):
     for r in rows[1:]:
         for k in range(6):
             assert int(r[1 + k]) == exp[f"s{k}"][r[0]]
+
+
+def test_integration_md_stub_runs(tmp_path, monkeypatch):
+    """the ctypes stub printed in INTEGRATION.md (what a reference maintainer would paste at the reads_counter seam)
+    is executed as written against libf2q_hip.so"""
+    import re
+    from dataclasses import dataclass
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    monkeypatch.setenv("F2Q_LIB", pkg().LIB_PATH)
+
+    @dataclass
+    class Features:
+        name: str
+        counts: int
+    ns = {"Features": Features}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    guides = synth.make_library(80, 20, 46)
+    fq = synth.make_fastq(synth.Spec(seed=70, n_reads=4000, read_len=64), guides)
+    path = tmp_path / "x.fastq.gz"
+    with gzip.open(path, "wb") as f:
+        f.write(fq)
+    param = default_param()
+    feats = {g: Features(f"n{i}", 0) for i, g in enumerate(guides)}
+    out = ns["reads_counter"](0, str(path), feats, param, {"failed_reads": set(), "passed_reads": {}})
+    orc = O.Oracle(features=[(f"n{i}", g) for i, g in enumerate(guides)], miss=1)
+    orc.count_fastq(fq)
+    assert [f.counts for f in out[0].values()] == orc.counts() and out[2] == orc.stats_dict()
+    ec = ns["reads_counter"](0, str(path), {}, default_param(**{"Running Mode": "EC"}), {})
+    orc2 = O.Oracle(mode="EC")
+    orc2.count_fastq(fq)
+    assert [(k, f.counts) for k, f in ec[0].items()] == list(zip(orc2.keys(), orc2.counts()))
