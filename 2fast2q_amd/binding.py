@@ -11,7 +11,7 @@ import numpy as np
 
 MAX_ITER = 16
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libf2q_hip.so")
+LIB_PATH = os.environ.get("F2Q_LIB_PATH") or os.path.join(_HERE, "lib", "libf2q_hip.so")   # override: diagnostic builds
 STAT_NAMES = ("reads", "perfect_counter", "imperfect_counter", "non_aligned_counter", "quality_failed")
 
 EXPORTS = (

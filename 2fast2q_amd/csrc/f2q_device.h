@@ -99,6 +99,7 @@ struct Accum {
     unsigned long long *stats;         // [5]
     uint32_t *slab;                    // [gridDim.x][n_features] per-workgroup histograms (or nullptr)
     unsigned long long *stat_slab;     // [gridDim.x][8] per-workgroup stats (or nullptr)
+    unsigned long long *stamp;         // diagnostic builds (-DF2Q_STAMP): per-phase cycle sums, else nullptr
 };
 
 struct EcDev {

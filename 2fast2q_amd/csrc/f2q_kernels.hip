@@ -303,6 +303,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
 // search, LDS histogram.  Extract+Count mode: single-word insert into the device table.
 #define F2Q_AN_THREADS 256
 #define F2Q_AN_WAVES (F2Q_AN_THREADS / 64)
+#define F2Q_AN_QCAP 512u          // entries per wave ring (power of two: the ring index is a mask, not a multiply)
 
 // odd geometry (negative-index slices, windows the 2-bit tables cannot hold): the byte-exact general routine
 // on a private copy of the read, rebuilt from the tile in memory so that the caller keeps nothing live for it
@@ -332,9 +333,9 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
 {
     constexpr int NQW = 8 * NW;
     extern __shared__ unsigned long long smem64[];
-    unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;
-    uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_V2_QCAP) + (threadIdx.x >> 6) * F2Q_V2_QCAP;
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_V2_QCAP) + F2Q_AN_WAVES * F2Q_V2_QCAP;
+    unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_AN_QCAP;
+    uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_AN_QCAP) + (threadIdx.x >> 6) * F2Q_AN_QCAP;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_AN_QCAP) + F2Q_AN_WAVES * F2Q_AN_QCAP;
     __shared__ uint32_t q_tails[F2Q_AN_WAVES];
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
@@ -349,6 +350,12 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     const int pk_len = (int)lib.pk.len;
     const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
     unsigned long long st[5] = {0, 0, 0, 0, 0};
+#ifdef F2Q_STAMP
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t0_, t1_;
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
     auto count_hit = [&](uint32_t idx) {
         if (USE_LDS) atomicAdd(&hist[idx], 1u);
@@ -358,6 +365,9 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
         const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + tid;
         const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + tid;
+#ifdef F2Q_STAMP
+        __builtin_amdgcn_sched_barrier(0); t0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
         const uint32_t l = pb.len ? gp(pb.len)[(uint64_t)tile * F2Q_TILE + tid] : pb.rmax;
         uint32_t LO[NW], HI[NW];
 #pragma unroll
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
             uint32_t Q[NQW];
 #pragma unroll
             for (int i = 0; i < NQW; i++)
-                Q[i] = __builtin_nontemporal_load(qp + (uint64_t)((uint32_t)i < pb.wq ? (uint32_t)i : pb.wq - 1u) * F2Q_TILE);
+                Q[i] = __builtin_nontemporal_load(qp + (uint64_t)i * F2Q_TILE);      // planar tiles always hold 8*NW quality rows
 #pragma unroll
             for (int cw = 0; cw < NW; cw++) {
                 uint32_t q8[8];
@@ -385,6 +395,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(0);                                   // loads + fail vectors
         if (l != F2Q_LEN_SKIP) {
             const int r = (int)(l & 0x7FFFu);
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
@@ -392,6 +403,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
             AnchorWin aw;
             if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, LO, HI, FLG, r, FW, FW, FW);
             else aw = anchor_window<NW, KB, KB>(run, LO, HI, FLG, r, FU, FD, FW);
+            STAMP(1);                               // anchor search + region tests
             const int L = aw.end - aw.start;
             if (aw.ok == 0) { st[4]++; st[0]++; }
             else if (aw.ok == 1 && !EC && (L < 1 || L > F2Q_REG_MAXLEN)) {
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                     const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
                     if (L == pk_len) {                                         // queued with its forced-mismatch mask
                         uint32_t at = atomicAdd(q_tail, 1u);
-                        queue[at % F2Q_V2_QCAP] = key; qforced[at % F2Q_V2_QCAP] = forced;
+                        queue[at % F2Q_AN_QCAP] = key; qforced[at % F2Q_AN_QCAP] = forced;
                     } else {
                         MinTrack t; t.init(run.miss);
                         lib_near(lib, key, L, spread32(forced), t);       // wide tables, in place (rare)
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                     const int e = packed_exact(lib, key);
                     if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
                     else if (!do_near) st[3]++;
-                    else { uint32_t at = atomicAdd(q_tail, 1u); queue[at % F2Q_V2_QCAP] = key; qforced[at % F2Q_V2_QCAP] = 0u; }
+                    else { uint32_t at = atomicAdd(q_tail, 1u); queue[at % F2Q_AN_QCAP] = key; qforced[at % F2Q_AN_QCAP] = 0u; }
                 } else {
                     // a window of another length than the packed tables index: wide tables, in place (rare)
                     const int e = lib_exact(lib, key, L);
@@ -459,27 +471,32 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 }
             }
         }
+        STAMP(2);                                   // key, probe, insert
         if (!EC && do_near) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
             while (tail - q_head >= 64u) {
                 uint32_t idx = 0;
-                int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
+                int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], &idx);
                 if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
                 q_head += 64u;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        STAMP(3);                                   // ring drain
     }
     if (!EC && do_near) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
         if (lane < tail - q_head) {
             uint32_t idx = 0;
-            int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
+            int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], &idx);
             if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
         }
     }
+#ifdef F2Q_STAMP
+    if (lane == 0 && acc.stamp) for (int i = 0; i < 4; i++) atomicAdd(&acc.stamp[i], tp[i]);
+#endif
     __shared__ unsigned long long st_lds[8];
     flush_stats(acc, st, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
     if (USE_LDS && !EC) {
@@ -1114,7 +1131,12 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
 static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
 {
     if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
-    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr};
+    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr, nullptr};
+#ifdef F2Q_STAMP
+    static unsigned long long *stamp_d = nullptr;
+    if (!stamp_d) { (void)hipMalloc((void **)&stamp_d, 64); (void)hipMemset(stamp_d, 0, 64); }
+    acc.stamp = stamp_d;
+#endif
     if (c->prm.mode == 1 && b->n_reads) {
         // worst case every read inserts a new key made of all its windows
         uint64_t key_bytes = b->dev_bytes;   // upper bound: no key is longer than the read's bytes + separators
@@ -1127,8 +1149,9 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         // packed anchored path
         const bool ecm = c->prm.mode == 1;
         const bool lds = !ecm && c->lib_h.n_features <= F2Q_HIST_MAX;
-        const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * 4u);
-        const size_t shmem = (size_t)F2Q_AN_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
+        uint32_t an_mult = 4u; { const char *e = getenv("F2Q_AN_GRID"); if (e && atoi(e) > 0) an_mult = (uint32_t)atoi(e); }
+        const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * an_mult);
+        const size_t shmem = (size_t)F2Q_AN_WAVES * F2Q_AN_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
         if (!ecm) {
             const size_t need = lds ? (size_t)grid * c->lib_h.n_features : 0;
             if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
@@ -1225,6 +1248,14 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
     }
     HIPC(c, hipEventRecord(c->ev_k1, c->stream));
     c->reads_seen += b->n_reads;
+#ifdef F2Q_STAMP
+    { unsigned long long h[4]; (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(h, acc.stamp, 32, hipMemcpyDeviceToHost);
+      (void)hipMemset(acc.stamp, 0, 64);
+      unsigned long long tot = h[0] + h[1] + h[2] + h[3];
+      if (tot) fprintf(stderr, "[stamp] loads+fail %.1f%%  anchors %.1f%%  key/probe %.1f%%  drain %.1f%%  (%.0f cycles/wave-tile)\n",
+                       100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot,
+                       (double)tot / ((double)b->pb.n_tiles * 4)); }
+#endif
     if (t) {
         HIPC(c, hipEventSynchronize(c->ev_k1));
         float ms = 0;
