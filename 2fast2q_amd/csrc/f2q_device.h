@@ -788,7 +788,8 @@ F2Q_HD uint32_t fixed4_flags(const FixedGeom &g, const U4 (&q)[QR], int j)
 }
 
 // pigeonhole search on the packed piece tables; forced2 = 2-bit-spaced mask of query positions that
-// mismatch every feature (non-ACGT symbols)
+// mismatch every feature (non-ACGT symbols).  The first slot of every piece's chain (up to 4 pieces) is
+// fetched before any chain is walked, so the usual m = 1 lookup costs one memory round trip, not two.
 F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTrack &t)
 {
     const uint32_t ib = lib.pk.ib;
@@ -796,14 +797,25 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
     const auto ptab = gp(lib.ptab);
     const int nforced = popc64(forced2);
     const uint64_t keep = ~(forced2 | (forced2 << 1));
-    for (uint32_t p = 0; p < lib.pk.n_pieces; p++) {
+    const uint32_t np = lib.pk.n_pieces;
+    uint32_t s0[4]; uint64_t v0[4];
+#pragma unroll
+    for (uint32_t p = 0; p < 4; p++) {
+        if (p < np) {
+            const PackedPiece pd = lib.pk.piece[p];
+            s0[p] = hash32((key >> pd.shift) & pd.mask, pd.bits);
+            v0[p] = ptab[pd.off + s0[p]];
+        } else { s0[p] = 0; v0[p] = KEY_EMPTY; }
+    }
+#pragma unroll
+    for (uint32_t p = 0; p < F2Q_MAX_PIECES; p++) {
+        if (p >= np) break;
         const PackedPiece pd = lib.pk.piece[p];
         if ((forced2 >> pd.shift) & pd.mask) continue;                       // this piece can never agree
-        const uint64_t pv = (key >> pd.shift) & pd.mask;
         const uint32_t m = (1u << pd.bits) - 1u;
-        uint32_t s = hash32(pv, pd.bits);
+        uint32_t s = p < 4 ? s0[p < 4 ? p : 0] : hash32((key >> pd.shift) & pd.mask, pd.bits);
+        uint64_t v = p < 4 ? v0[p < 4 ? p : 0] : ptab[pd.off + s];
         for (;;) {
-            uint64_t v = ptab[pd.off + s];
             if (v == KEY_EMPTY) break;
             uint64_t x = (v >> ib) ^ key;
             if (((x >> pd.shift) & pd.mask) == 0) {
@@ -816,6 +828,7 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
                 if (!dup) t.offer(ham2(x & keep) + nforced, (uint32_t)(v & imask));
             }
             s = (s + 1) & m;
+            v = ptab[pd.off + s];
         }
     }
 }

@@ -120,10 +120,6 @@ __device__ __noinline__ int slow_read(const RunDev *run, const LibDev *lib, cons
 {
     return fixed_lane(*run, *lib, *pb, tile, slot, *idx);
 }
-__device__ __noinline__ int near_read(const RunDev *run, const LibDev *lib, uint64_t key, uint32_t forced, uint32_t *idx)
-{
-    return packed_near_decide(*run, *lib, key, forced, *idx);
-}
 
 // NQ / NB: number of quality / base rows under the window when known at compile time (the common
 // geometries get their own instantiation so that all row loads sit in one basic block and issue
@@ -139,16 +135,14 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;                 // keys
     uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + (threadIdx.x >> 6) * F2Q_V2_QCAP;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + F2Q_V2_WAVES * F2Q_V2_QCAP;  // USE_LDS
-    __shared__ uint32_t q_tails[F2Q_V2_WAVES];
+
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
     const uint32_t nf = lib.n_features;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (USE_LDS) for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) hist[i] = 0;
-    if (tid < F2Q_V2_WAVES) q_tails[tid] = 0;
     __syncthreads();
-    uint32_t *q_tail = &q_tails[wave];
-    uint32_t q_head = 0;
+    uint32_t q_head = 0, q_tail = 0;          // the ring belongs to this wave alone: head and tail live in (uniform) registers
     const FixedGeom g = fixed_geom(run);
     const int need = g.st + g.L;
     const bool do_near = run.miss > 0;
@@ -157,6 +151,12 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     const uint64_t imask = (1ull << ib) - 1ull;
     const auto ptab = gp(lib.ptab);
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+#ifdef F2Q_STAMP
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t0_ = 0, t1_;
+#define STAMP4(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP4(i) do {} while (0)
+#endif
 
     auto count_hit = [&](uint32_t idx) {
         if (USE_LDS) atomicAdd(&hist[idx], 1u);
@@ -165,6 +165,9 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
 
     for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
         const uint32_t tile = base + wave;
+#ifdef F2Q_STAMP
+        __builtin_amdgcn_sched_barrier(0); t0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
         int res[4] = {R_SKIP, R_SKIP, R_SKIP, R_SKIP};
         uint64_t key[4] = {0, 0, 0, 0};
         uint32_t forced[4] = {0, 0, 0, 0};
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                     }
                 }
             }
+            STAMP4(0);                              // row loads, Phred, keys
             // exact probes: up to 4 reads x 2 slots in flight per lane
             uint32_t s[4]; bool pend[4];
 #pragma unroll
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                     else s[j] = (s[j] + 2u) & exm;
                 }
             }
+            STAMP4(1);                              // exact probes
             uint32_t npush = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -253,8 +258,13 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 st0 += (res[j] != R_SKIP); st1 += (res[j] == R_PERFECT); st2 += (res[j] == R_IMPERFECT);
                 st3 += (res[j] == R_NONALIGNED); st4 += (res[j] == R_QFAIL);
             }
-            if (npush) {
-                uint32_t at = atomicAdd(q_tail, npush);
+            {
+                // ring slots by a wave prefix sum of npush (0..4) over three ballots -- no LDS atomics
+                const unsigned long long b0 = __ballot(npush & 1u), b1 = __ballot(npush & 2u), b2 = __ballot(npush & 4u);
+                uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))
+                              + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u))
+                              + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+                q_tail += (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (res[j] == R_NEAR || res[j] == R_FORCED) {
@@ -262,28 +272,33 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                     }
             }
         }
+        STAMP4(2);                                  // histogram, slow reads, ring push
         if (do_near) {
             // LDS operations of one wave complete in order; the fence keeps the compiler from moving the reads up
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+            const uint32_t tail = q_tail;
             while (tail - q_head >= 64u) {
                 uint32_t idx = 0;
-                int r = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
+                int r = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], idx);
                 if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
                 q_head += 64u;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        STAMP4(3);                                  // ring drain
     }
     if (do_near) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+        const uint32_t tail = q_tail;
         if (lane < tail - q_head) {
             uint32_t idx = 0;
-            int r = near_read(runp, libp, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], &idx);
+            int r = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], idx);
             if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
         }
     }
+#ifdef F2Q_STAMP
+    if (lane == 0 && acc.stamp) for (int i = 0; i < 4; i++) atomicAdd(&acc.stamp[i], tp[i]);
+#endif
     __shared__ unsigned long long st_lds[8];
     unsigned long long stv[5] = {st0, st1, st2, st3, st4};
     flush_stats(acc, stv, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
@@ -336,16 +351,13 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_AN_QCAP;
     uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_AN_QCAP) + (threadIdx.x >> 6) * F2Q_AN_QCAP;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_AN_QCAP) + F2Q_AN_WAVES * F2Q_AN_QCAP;
-    __shared__ uint32_t q_tails[F2Q_AN_WAVES];
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
     const uint32_t nf = lib.n_features;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (USE_LDS && !EC) for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) hist[i] = 0;
-    if (tid < F2Q_AN_WAVES) q_tails[tid] = 0;
     __syncthreads();
-    uint32_t *q_tail = &q_tails[wave];
-    uint32_t q_head = 0;
+    uint32_t q_head = 0, q_tail = 0;          // this wave's ring: head and tail in (uniform) registers
     const bool do_near = run.miss > 0;
     const int pk_len = (int)lib.pk.len;
     const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
@@ -396,6 +408,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
         }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(0);                                   // loads + fail vectors
+        bool push = false; uint64_t push_key = 0; uint32_t push_forced = 0;
         if (l != F2Q_LEN_SKIP) {
             const int r = (int)(l & 0x7FFFu);
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
@@ -441,10 +454,8 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 } else if (!do_near || __popc(forced) > run.miss) st[3]++;
                 else {
                     const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
-                    if (L == pk_len) {                                         // queued with its forced-mismatch mask
-                        uint32_t at = atomicAdd(q_tail, 1u);
-                        queue[at % F2Q_AN_QCAP] = key; qforced[at % F2Q_AN_QCAP] = forced;
-                    } else {
+                    if (L == pk_len) { push = true; push_key = key; push_forced = forced; }   // queued with its forced mask
+                    else {
                         MinTrack t; t.init(run.miss);
                         lib_near(lib, key, L, spread32(forced), t);       // wide tables, in place (rare)
                         if (t.cnt == 1) { count_hit(t.idx); st[2]++; } else st[3]++;
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                     const int e = packed_exact(lib, key);
                     if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
                     else if (!do_near) st[3]++;
-                    else { uint32_t at = atomicAdd(q_tail, 1u); queue[at % F2Q_AN_QCAP] = key; qforced[at % F2Q_AN_QCAP] = 0u; }
+                    else { push = true; push_key = key; push_forced = 0u; }
                 } else {
                     // a window of another length than the packed tables index: wide tables, in place (rare)
                     const int e = lib_exact(lib, key, L);
@@ -471,13 +482,22 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 }
             }
         }
+        if (!EC && do_near) {
+            // ring slot by ballot prefix (no LDS atomic)
+            const unsigned long long pm = __ballot(push);
+            if (push) {
+                const uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                queue[at % F2Q_AN_QCAP] = push_key; qforced[at % F2Q_AN_QCAP] = push_forced;
+            }
+            q_tail += (uint32_t)__popcll(pm);
+        }
         STAMP(2);                                   // key, probe, insert
         if (!EC && do_near) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+            const uint32_t tail = q_tail;
             while (tail - q_head >= 64u) {
                 uint32_t idx = 0;
-                int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], &idx);
+                int rr = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], idx);
                 if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
                 q_head += 64u;
             }
@@ -487,10 +507,10 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     }
     if (!EC && do_near) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint32_t tail = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)q_tail);
+        const uint32_t tail = q_tail;
         if (lane < tail - q_head) {
             uint32_t idx = 0;
-            int rr = near_read(runp, libp, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], &idx);
+            int rr = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], idx);
             if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
         }
     }
