@@ -161,3 +161,17 @@ def test_integration_md_stub_runs(tmp_path, monkeypatch):
     orc2 = O.Oracle(mode="EC")
     orc2.count_fastq(fq)
     assert [(k, f.counts) for k, f in ec[0].items()] == list(zip(orc2.keys(), orc2.counts()))
+
+
+def test_console_script_like_the_reference_test(tmp_path):
+    """reference tests/test_cli.py:5-25 verbatim in spirit: run `2fast2q -c -t` as a subprocess in an empty
+    directory; exit code 0, exactly one output folder, exactly 6 files, compiled.csv among them"""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "2fast2q"), "-c", "-t"], cwd=tmp_path,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert res.returncode == 0, res.stderr
+    subdirs = [d for d in tmp_path.iterdir() if d.is_dir()]
+    assert len(subdirs) == 1
+    files = list(subdirs[0].iterdir())
+    assert len(files) == 6 and (subdirs[0] / "compiled.csv").exists()
