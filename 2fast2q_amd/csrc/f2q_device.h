@@ -100,6 +100,7 @@ struct Accum {
     uint32_t *slab;                    // [gridDim.x][n_features] per-workgroup histograms (or nullptr)
     unsigned long long *stat_slab;     // [gridDim.x][8] per-workgroup stats (or nullptr)
     unsigned long long *stamp;         // diagnostic builds (-DF2Q_STAMP): per-phase cycle sums, else nullptr
+    uint32_t *hit_buf;                 // large libraries: feature index per read slot (0xFFFFFFFF = none), histogrammed by k_hist_ranges
 };
 
 struct EcDev {

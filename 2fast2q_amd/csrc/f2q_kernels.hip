@@ -135,6 +135,8 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;                 // keys
     uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + (threadIdx.x >> 6) * F2Q_V2_QCAP;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + F2Q_V2_WAVES * F2Q_V2_QCAP;  // USE_LDS
+    // !USE_LDS (library too large for an LDS histogram): the same region holds the read slot of every ring entry
+    uint32_t *qslot = hist + (threadIdx.x >> 6) * F2Q_V2_QCAP;
 
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
@@ -158,9 +160,10 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
 #define STAMP4(i) do {} while (0)
 #endif
 
-    auto count_hit = [&](uint32_t idx) {
+    // a hit: LDS histogram, or (large library) the feature index is stored at the read's slot for k_hist_ranges
+    auto count_hit = [&](uint32_t idx, uint64_t slot) {
         if (USE_LDS) atomicAdd(&hist[idx], 1u);
-        else acc_add(&acc.counts[idx], 1ull);
+        else gpw(acc.hit_buf)[slot] = idx;
     };
 
     for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
@@ -237,9 +240,9 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 for (int j = 0; j < 4; j++) {
                     if (!pend[j]) continue;
                     if (v0[j] == KEY_EMPTY) pend[j] = false;
-                    else if ((v0[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v0[j] & imask)); }
+                    else if ((v0[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v0[j] & imask), (uint64_t)tile * F2Q_TILE + 4u * lane + j); }
                     else if (v1[j] == KEY_EMPTY) pend[j] = false;
-                    else if ((v1[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v1[j] & imask)); }
+                    else if ((v1[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v1[j] & imask), (uint64_t)tile * F2Q_TILE + 4u * lane + j); }
                     else s[j] = (s[j] + 2u) & exm;
                 }
             }
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 if (res[j] == R_SLOW) {                    // clipped window / odd geometry: the one-read routine
                     uint32_t idx = 0;
                     int r1 = slow_read(runp, libp, &pb, tile, 4u * lane + (uint32_t)j, &idx);
-                    if (r1 == 1 || r1 == 2) count_hit(idx);
+                    if (r1 == 1 || r1 == 2) count_hit(idx, (uint64_t)tile * F2Q_TILE + 4u * lane + j);
                     res[j] = r1;
                 } else if (res[j] == R_NEAR) {
                     if (do_near) npush++; else res[j] = R_NONALIGNED;
@@ -268,7 +271,9 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (res[j] == R_NEAR || res[j] == R_FORCED) {
-                        queue[at % F2Q_V2_QCAP] = key[j]; qforced[at % F2Q_V2_QCAP] = forced[j]; at++;
+                        queue[at % F2Q_V2_QCAP] = key[j]; qforced[at % F2Q_V2_QCAP] = forced[j];
+                        if (!USE_LDS) qslot[at % F2Q_V2_QCAP] = tile * F2Q_TILE + 4u * lane + (uint32_t)j;   // slot inside the block (< 2^32)
+                        at++;
                     }
             }
         }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
             while (tail - q_head >= 64u) {
                 uint32_t idx = 0;
                 int r = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], idx);
-                if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
+                if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx, USE_LDS ? 0u : qslot[(q_head + lane) % F2Q_V2_QCAP]); st2++; } else st3++;
                 q_head += 64u;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
         if (lane < tail - q_head) {
             uint32_t idx = 0;
             int r = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], idx);
-            if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st2++; } else st3++;
+            if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx, USE_LDS ? 0u : qslot[(q_head + lane) % F2Q_V2_QCAP]); st2++; } else st3++;
         }
     }
 #ifdef F2Q_STAMP
@@ -526,19 +531,45 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     }
 }
 
+// Large libraries (no per-workgroup LDS histogram of the whole library): the counting kernel leaves the feature index
+// of every read in hit_buf; here workgroup (range, part) histograms the indices of its part that fall into its range
+// of F2Q_HIST_MAX features in LDS and writes that stretch of slab row `part`.  hit_buf is read n_ranges times, from
+// the Infinity Cache when it fits (4 B per read).
+__global__ __launch_bounds__(1024) void k_hist_ranges(const uint32_t *__restrict__ hit_buf, uint64_t n_slots, uint32_t nf,
+                                                       uint32_t n_parts, uint32_t *__restrict__ slab)
+{
+    extern __shared__ uint32_t rh[];
+    const uint32_t range = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
+    const uint32_t f0 = range * F2Q_HIST_MAX, fn = (nf - f0) < F2Q_HIST_MAX ? (nf - f0) : F2Q_HIST_MAX;
+    for (uint32_t i = threadIdx.x; i < fn; i += 1024u) rh[i] = 0;
+    __syncthreads();
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint64_t n4 = n_slots / 4;                       // n_slots is a multiple of the tile size
+    const auto hb = (const v4 F2Q_GLOBAL *)hit_buf;
+    for (uint64_t i = (uint64_t)part * 1024u + threadIdx.x; i < n4; i += (uint64_t)n_parts * 1024u) {
+        const v4 v = hb[i];
+        const uint32_t e[4] = {v.x - f0, v.y - f0, v.z - f0, v.w - f0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (e[k] < fn) atomicAdd(&rh[e[k]], 1u);   // 0xFFFFFFFF - f0 is never < fn
+    }
+    __syncthreads();
+    auto row = (uint32_t F2Q_GLOBAL *)slab + (uint64_t)part * nf + f0;
+    for (uint32_t i = threadIdx.x; i < fn; i += 1024u) row[i] = rh[i];
+}
+
 // counts[f] += sum over workgroups of slab[w][f].  Block = 64 features x 4 row lanes; grid.y splits
 // the rows further so that every thread has ~16 independent loads in flight.
 #define F2Q_RED_SPLIT 8u
 __global__ __launch_bounds__(256) void k_reduce_slabs(const uint32_t *__restrict__ slab, uint32_t n_rows, uint32_t nf,
                                                        unsigned long long *__restrict__ counts,
-                                                       const unsigned long long *__restrict__ stat_slab,
+                                                       const unsigned long long *__restrict__ stat_slab, uint32_t n_stat_rows,
                                                        unsigned long long *__restrict__ stats)
 {
     __shared__ unsigned long long part[256];
     if (blockIdx.x == 0 && blockIdx.y == 0 && stat_slab) {          // the 5 reference counters: rows of 8
         const uint32_t k = threadIdx.x & 7u, sub = threadIdx.x >> 3;   // 32 row lanes x 8 columns
         unsigned long long sv = 0;
-        if (k < 5) for (uint32_t w = sub; w < n_rows; w += 32u) sv += stat_slab[(uint64_t)w * 8u + k];
+        if (k < 5) for (uint32_t w = sub; w < n_stat_rows; w += 32u) sv += stat_slab[(uint64_t)w * 8u + k];
         part[threadIdx.x] = sv;
         __syncthreads();
         if (threadIdx.x < 5) {
@@ -852,6 +883,8 @@ struct f2q_ctx {
     size_t slab_n = 0;
     unsigned long long *stat_slab_d = nullptr;
     size_t stat_slab_n = 0;
+    uint32_t *hit_buf_d = nullptr;       // large libraries: feature index per read slot of the block being counted
+    size_t hit_buf_n = 0;
     // Extract+Count table
     EcDev ec{};
     std::vector<void *> ec_allocs;
@@ -1023,6 +1056,7 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->synth_keys_d) (void)hipFree(c->synth_keys_d);
     if (c->slab_d) (void)hipFree(c->slab_d);
     if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
+    if (c->hit_buf_d) (void)hipFree(c->hit_buf_d);
     if (c->run_d) (void)hipFree(c->run_d);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -1151,7 +1185,7 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
 static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
 {
     if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
-    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr, nullptr};
+    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr, nullptr, nullptr};
 #ifdef F2Q_STAMP
     static unsigned long long *stamp_d = nullptr;
     if (!stamp_d) { (void)hipMalloc((void **)&stamp_d, 64); (void)hipMemset(stamp_d, 0, 64); }
@@ -1209,7 +1243,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         launches++;
         if (lds && c->lib_h.n_features) {
             hipLaunchKernelGGL(k_reduce_slabs, dim3((c->lib_h.n_features + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
-                               c->slab_d, grid, c->lib_h.n_features, acc.counts, c->stat_slab_d, acc.stats);
+                               c->slab_d, grid, c->lib_h.n_features, acc.counts, c->stat_slab_d, grid, acc.stats);
             HIPC(c, hipGetLastError());
             launches++;
         }
@@ -1220,13 +1254,17 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         if (v2) {
             const uint32_t wgs = (b->pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
-            const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
+            const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 4);
             const FixedGeom fg = fixed_geom(c->run_h);
             const bool spec52 = !c->force_generic && fg.nq == 5 && fg.nb == 2 && c->run_h.thr >= 33;
             auto kern = lds ? (spec52 ? k_count_fixed4<true, 5, 2> : k_count_fixed4<true, 0, 0>)
                             : (spec52 ? k_count_fixed4<false, 5, 2> : k_count_fixed4<false, 0, 0>);
-            if (lds) {
-                const size_t need = (size_t)grid * c->lib_h.n_features;
+            const uint32_t nf_ = c->lib_h.n_features;
+            const uint32_t n_ranges = lds ? 1u : (nf_ + F2Q_HIST_MAX - 1) / F2Q_HIST_MAX;
+            const uint32_t n_parts = lds ? grid : std::max<uint32_t>(1u, (uint32_t)c->n_cu / n_ranges);
+            {
+                // slab rows: one per counting workgroup (LDS histogram) or one per part of k_hist_ranges; stats rows per workgroup
+                const size_t need = (size_t)n_parts * nf_;
                 if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
                     if (c->slab_d) (void)hipFree(c->slab_d);
                     if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
@@ -1238,11 +1276,27 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
                 acc.slab = c->slab_d;
                 acc.stat_slab = c->stat_slab_d;
             }
+            if (!lds) {
+                if (b->pb.n_slots > c->hit_buf_n) {
+                    if (c->hit_buf_d) (void)hipFree(c->hit_buf_d);
+                    c->hit_buf_d = nullptr; c->hit_buf_n = 0;
+                    HIPC(c, hipMalloc((void **)&c->hit_buf_d, b->pb.n_slots * sizeof(uint32_t)));
+                    c->hit_buf_n = b->pb.n_slots;
+                }
+                HIPC(c, hipMemsetAsync(c->hit_buf_d, 0xFF, b->pb.n_slots * sizeof(uint32_t), c->stream));
+                acc.hit_buf = c->hit_buf_d;
+            }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, b->pb, acc);
-            if (lds && c->lib_h.n_features) {
+            HIPC(c, hipGetLastError());
+            if (!lds && nf_) {
+                hipLaunchKernelGGL(k_hist_ranges, dim3(n_ranges * n_parts), dim3(1024), (size_t)F2Q_HIST_MAX * 4, c->stream,
+                                   c->hit_buf_d, (uint64_t)b->pb.n_slots, nf_, n_parts, c->slab_d);
                 HIPC(c, hipGetLastError());
-                hipLaunchKernelGGL(k_reduce_slabs, dim3((c->lib_h.n_features + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
-                                   c->slab_d, grid, c->lib_h.n_features, acc.counts, c->stat_slab_d, acc.stats);
+                launches++;
+            }
+            if (nf_) {
+                hipLaunchKernelGGL(k_reduce_slabs, dim3((nf_ + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
+                                   c->slab_d, n_parts, nf_, acc.counts, c->stat_slab_d, grid, acc.stats);
                 launches++;
             }
         } else {

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (rehearsal)")
     ap.add_argument("--miss", type=int, default=None, help="override --m (experiments)")
+    ap.add_argument("--guides", type=int, default=0, help="override the library size (experiments)")
     ap.add_argument("--phred", type=int, default=30, help="override --ph (experiments)")
     ap.add_argument("--ms", type=int, default=1, help="--msu/--msd of the anchored workloads (experiments)")
     ap.add_argument("--read-len", type=int, default=150, help="override the read length (experiments)")
@@ -103,6 +104,8 @@ def main():
         w["n_reads"] = a.reads
     if a.miss is not None:
         w["miss"] = a.miss
+    if a.guides:
+        w["n_guides"] = a.guides
     guides = pkg.binding.synth_library(w["lib_seed"], w["n_guides"], 20)
     n = w["n_reads"]
     if w.get("anchored"):

@@ -84,7 +84,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
     size_t used = frame_fastq(buf, n, recs);
     HostPacked hp;
     pack_records(e->plan, recs, hp);
-    Accum acc{e->acc.data(), e->acc.data() + e->ix.n_features, nullptr, nullptr, nullptr};
+    Accum acc{e->acc.data(), e->acc.data() + e->ix.n_features, nullptr, nullptr, nullptr, nullptr};
     PackedBlock pb{};
     pb.n_tiles = hp.n_tiles; pb.wb = hp.wb; pb.wq = hp.wq; pb.rmax = hp.rmax; pb.n_slots = (uint64_t)hp.n_tiles * F2Q_TILE;
     pb.bases = hp.bases.data(); pb.qual = hp.qual.data(); pb.len = hp.len.data(); pb.planar_nw = hp.planar_nw;
