@@ -188,8 +188,10 @@ inline size_t frame_fastq(const uint8_t *buf, size_t nbytes, std::vector<Rec> &o
 inline PackPlan make_plan(const RunDev &run)
 {
     PackPlan pl;
-    pl.fast_fixed = run.mode == 0 && run.fixed && run.n_iter == 1 && run.start[0] >= 0 && run.length >= 0 &&
-                    run.length <= F2Q_REG_MAXLEN && run.start[0] + run.length <= F2Q_PACK_MAXLEN;
+    // Counter mode: windows up to 31 bases (2-bit library tables); Extract+Count: up to 29 (single-word key table)
+    pl.fast_fixed = run.fixed && run.n_iter == 1 && run.start[0] >= 0 && run.length >= 0 &&
+                    run.length <= (run.mode == 0 ? F2Q_REG_MAXLEN : F2Q_EC64_MAXLEN) &&
+                    run.start[0] + run.length <= F2Q_PACK_MAXLEN;
     pl.need = pl.fast_fixed ? run.start[0] + run.length : 0;
     pl.from = pl.fast_fixed ? run.start[0] : 0;
     pl.fast_anchor = !run.fixed && run.n_iter == 1 && run.anchors_packed && run.msu >= 0 && run.msd >= 0 &&

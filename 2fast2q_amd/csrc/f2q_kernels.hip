@@ -315,6 +315,66 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     }
 }
 
+// Extract+Count with a fixed window (--mo EC --st/--l): same tile walk and Phred test as k_count_fixed4, but every
+// passing window (clipped to the read, possibly empty) is a key of the single-word device table -- no library.
+__global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev *__restrict__ runp, EcDev ec, PackedBlock pb,
+                                                                    Accum acc, uint64_t read_base)
+{
+    const RunDev &run = *runp;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const FixedGeom g = fixed_geom(run);
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
+        const uint32_t tile = base + wave;
+        if (tile >= pb.n_tiles) continue;
+        U4 brow[F2Q_MAXBROWS], qrow[F2Q_MAXQROWS];
+        const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane;
+        const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane;
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXBROWS; r++) {
+            uint32_t row = (uint32_t)g.bw0 + (uint32_t)(r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
+            row = row < pb.wb ? row : pb.wb - 1u;
+            brow[r] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
+        }
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXQROWS; r++) {
+            const uint32_t want = (uint32_t)g.qw0 + (uint32_t)(r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
+            const uint32_t row = want < pb.wq ? want : pb.wq - 1u;
+            // a row past the tile's last one holds no byte of any read of the block: it must test as "nothing fails"
+            qrow[r] = (g.add_hi && want < pb.wq) ? ld_u4<true>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
+        }
+        uint32_t len01 = 0, len23 = 0;
+        if (pb.len) {
+            typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+            v2 lv = *(const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)tile * F2Q_TILE + 4u * lane);
+            len01 = lv.x; len23 = lv.y;
+        }
+        uint32_t bad[4] = {0, 0, 0, 0};
+        if (g.add_hi) {
+#pragma unroll
+            for (int r = 0; r < F2Q_MAXQROWS; r++)
+                if (r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+            if (l == F2Q_LEN_SKIP) continue;
+            st[0]++;
+            // bytes past the end of a short read are stored as 0 and never fail, so bad[] already is the clipped test
+            if (bad[j]) { st[4]++; continue; }
+            const int rl = (int)(l & 0x7FFFu);
+            int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;             // Python slice clipping (:354)
+            if (L < 0) L = 0;
+            const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
+            const uint64_t slot = (uint64_t)tile * F2Q_TILE + 4u * lane + (uint32_t)j;
+            ec64_insert(ec, key, L, read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
+            st[1]++;
+        }
+    }
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
+}
+
 // ---- fast path, anchored ------------------------------------------------------------------------------
 // One lane = one read of a planar tile (bit-planes, see f2q_device.h).  Every byte of every read is
 // needed here (the anchors can sit anywhere, the Phred tests follow them), so this is the kernel that
@@ -1247,6 +1307,12 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             HIPC(c, hipGetLastError());
             launches++;
         }
+    } else if (b->pb.n_tiles && c->prm.mode == 1) {
+        const uint32_t wgs = (b->pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
+        const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 4u);
+        hipLaunchKernelGGL(k_extract_fixed4, dim3(grid), dim3(F2Q_V2_THREADS), 0, c->stream, c->run_d, c->ec, b->pb, acc, c->reads_seen);
+        HIPC(c, hipGetLastError());
+        launches++;
     } else if (b->pb.n_tiles) {
         const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
         const bool v2 = !c->force_v1 && c->lib_h.pk.len == (uint32_t)c->run_h.length && c->lib_h.pk.len > 0 &&

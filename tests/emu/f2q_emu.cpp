@@ -184,6 +184,42 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             }
         e->anchor_reads += hp.n_clean;
     } else {
+    if (e->run.mode == 1) {
+        // k_extract_fixed4: Extract+Count with a fixed window on packed tiles
+        const FixedGeom g = fixed_geom(e->run);
+        for (uint32_t t = 0; t < hp.n_tiles; t++)
+            for (uint32_t lane = 0; lane < 64; lane++) {
+                U4 b[F2Q_MAXBROWS], qr[F2Q_MAXQROWS]; uint32_t bad[4] = {0, 0, 0, 0};
+                const uint32_t *qp = pb.qual + ((uint64_t)t * pb.wq) * F2Q_TILE + 4 * lane;
+                const uint32_t *bp = pb.bases + ((uint64_t)t * pb.wb) * F2Q_TILE + 4 * lane;
+                for (int r = 0; r < F2Q_MAXBROWS; r++) {
+                    uint32_t row = g.bw0 + (r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
+                    row = row < pb.wb ? row : pb.wb - 1;
+                    const uint32_t *p = bp + (uint64_t)row * F2Q_TILE; b[r] = U4{p[0], p[1], p[2], p[3]};
+                }
+                for (int r = 0; r < F2Q_MAXQROWS; r++) {
+                    const uint32_t want = g.qw0 + (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
+                    const uint32_t row = want < pb.wq ? want : pb.wq - 1;
+                    const uint32_t *p = qp + (uint64_t)row * F2Q_TILE;
+                    qr[r] = (g.add_hi && want < pb.wq) ? U4{p[0], p[1], p[2], p[3]} : U4{0, 0, 0, 0};
+                }
+                if (g.add_hi)
+                    for (int r = 0; r < F2Q_MAXQROWS; r++)
+                        if (r < g.nq) fixed4_qrow(g, r, qr[r], bad);
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
+                    if (l == F2Q_LEN_SKIP) continue;
+                    acc.stats[0]++; e->v2_reads++;
+                    if (bad[j]) { acc.stats[4]++; continue; }
+                    const int rl = (int)(l & 0x7FFFu);
+                    int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;
+                    if (L < 0) L = 0;
+                    const uint64_t key = fixed4_key(g, b, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
+                    ec64_insert(e->ec, key, L, e->reads_seen + hp_index[(uint64_t)t * F2Q_TILE + 4 * lane + j]);
+                    acc.stats[1]++;
+                }
+            }
+    } else {
     const bool v2 = e->use_v2 && e->lib.pk.len == (uint32_t)e->run.length && e->lib.pk.len > 0 && e->lib.n_irregular == 0;
     if (v2) {
         // the v2 kernel's per-lane sequence: 4 reads per lane from 16-byte row loads, packed tables
@@ -241,6 +277,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             if (res == 1 || res == 2) acc.counts[idx]++;
             if (res) { acc.stats[0]++; acc.stats[res]++; }
         }
+    }
     }
     for (size_t g = 0; g < hp.g_len.size(); g++) {
         const uint8_t *seq = hp.raw.data() + hp.g_off[g];

@@ -376,3 +376,20 @@ def test_full_size_config5_cross_paths(P, monkeypatch):
     _, sp2, ecp, _ = _full(P, monkeypatch, {}, lib, sl, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
     _, sg2, ecg, _ = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, sl, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
     assert sp2 == sg2 and ecp == ecg
+
+
+@pytest.mark.parametrize("start,length,rl", [(0, 20, 150), (7, 29, 60), (3, 12, 14), (10, 8, 9), (0, 0, 30), (5, 30, 80)])
+def test_extract_count_fixed_window_gpu(P, start, length, rl):
+    guides = synth.make_library(60, max(8, min(length, 20)), 777)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=start + length, n_reads=20000, read_len=rl, start=min(start, rl - 1),
+                                                       p_lowq=0.2), guides), 2, rate=0.01)
+    fq += synth.make_fastq(synth.Spec(seed=1, n_reads=200, read_len=max(1, start)), guides)
+    kw = dict(mode="EC", start=str(start), length=length)
+    o = O.Oracle(**kw)
+    o.count_fastq(fq)
+    with P.Counter(**kw) as c:
+        _, t = c.count_block(fq, want_timing=True)
+        _, stats = c.read_counts()
+        assert list(stats) == o.stats()
+        assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts()))
+        assert (t["fast_reads"] > 0) == (length <= 29)

@@ -194,3 +194,21 @@ def test_packed_anchor_with_odd_symbols(anchors):
             assert counts == o.counts() and fast > 0.5 * stats[0]
         else:
             assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
+
+
+@pytest.mark.parametrize("start,length,rl", [(0, 20, 150), (7, 29, 60), (3, 12, 14), (10, 8, 9), (0, 0, 30), (5, 30, 80)])
+def test_extract_count_fixed_window(start, length, rl):
+    """Extract+Count with --st/--l on the packed path: clipped and empty windows, odd symbols, Phred filter"""
+    guides = synth.make_library(60, max(8, min(length, 20)), 777)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=start + length, n_reads=2500, read_len=rl, start=min(start, rl - 1),
+                                                       p_lowq=0.2), guides), 2, rate=0.01)
+    fq += synth.make_fastq(synth.Spec(seed=1, n_reads=200, read_len=max(1, start)), guides)     # reads ending before the window
+    kw = dict(mode="EC", start=str(start), length=length)
+    o = O.Oracle(**kw)
+    o.count_fastq(fq)
+    e = Emu(**kw)
+    e.count_block(fq)
+    _, stats, fast, gen = e.read()
+    assert stats == o.stats()
+    assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
+    assert (fast > 0) == (length <= 29)          # windows longer than 29 bases use the byte-string table (general path)
