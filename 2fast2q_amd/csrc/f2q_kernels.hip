@@ -1643,7 +1643,8 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
 {
     if (!c || !path) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
-    const size_t CH = (size_t)256 << 20;
+    size_t CH = (size_t)256 << 20;                 // bytes of text per block; F2Q_FILE_CHUNK overrides (tests)
+    { const char *e = getenv("F2Q_FILE_CHUNK"); if (e && atol(e) >= 4096) CH = (size_t)atol(e); }
     // gzip by content (1f 8b), like gzip.open() by extension upstream (:567); plain files are read() straight
     // into the pinned buffer, without zlib's pass-through copy
     FILE *pf = fopen(path, "rb");

@@ -175,3 +175,29 @@ def test_console_script_like_the_reference_test(tmp_path):
     assert len(subdirs) == 1
     files = list(subdirs[0].iterdir())
     assert len(files) == 6 and (subdirs[0] / "compiled.csv").exists()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+@pytest.mark.parametrize("chunk", ["4096", "65536", "1000003"])
+def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk):
+    """f2q_count_file streams a file in blocks: records and lines that straddle a block boundary, a block that
+    holds no complete record, CRLF, and an unterminated last line must not change the counts"""
+    monkeypatch.setenv("F2Q_FILE_CHUNK", chunk)
+    guides = synth.make_library(120, 20, 47)
+    fq = synth.make_fastq(synth.Spec(seed=80, n_reads=9000, read_len=151), guides)
+    fq = fq.replace(b"\n", b"\r\n", 3000)                      # some CRLF line ends
+    fq += b"@long\n" + b"ACGT" * 3000 + b"\n+\n" + b"I" * 12000 + b"\n"      # a 12 kb read: longer than the smallest chunk
+    fq += synth.make_fastq(synth.Spec(seed=81, n_reads=500, read_len=40), guides)[:-1]   # no final newline
+    path = tmp_path / ("f.fastq.gz" if gz else "f.fastq")
+    (gzip.open(path, "wb") if gz else open(path, "wb")).write(fq)
+    for kw in (dict(miss=1), dict(mode="EC", upstream="ACGT", length=9)):
+        orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)] if "mode" not in kw else None, **kw)
+        orc.count_fastq(fq)
+        with pkg().Counter(features=guides if "mode" not in kw else None, **kw) as c:
+            t, trunc = c.count_file(str(path))
+            counts, stats = c.read_counts()
+            assert not trunc and list(stats) == orc.stats() and t["reads"] == orc.stats()[0]
+            if "mode" not in kw:
+                assert list(counts) == orc.counts()
+            else:
+                assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
