@@ -799,14 +799,15 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
     const int nforced = popc64(forced2);
     const uint64_t keep = ~(forced2 | (forced2 << 1));
     const uint32_t np = lib.pk.n_pieces;
-    uint32_t s0[4]; uint64_t v0[4];
+    uint32_t s0[4]; uint64_t v0[4], v1[4];
 #pragma unroll
     for (uint32_t p = 0; p < 4; p++) {
         if (p < np) {
             const PackedPiece pd = lib.pk.piece[p];
             s0[p] = hash32((key >> pd.shift) & pd.mask, pd.bits);
-            v0[p] = ptab[pd.off + s0[p]];
-        } else { s0[p] = 0; v0[p] = KEY_EMPTY; }
+            v0[p] = ptab[pd.off + s0[p]];                                   // the chain's first two slots: at load
+            v1[p] = ptab[pd.off + ((s0[p] + 1u) & ((1u << pd.bits) - 1u))];  // factor <= 0.25 most chains end here
+        } else { s0[p] = 0; v0[p] = KEY_EMPTY; v1[p] = KEY_EMPTY; }
     }
 #pragma unroll
     for (uint32_t p = 0; p < F2Q_MAX_PIECES; p++) {
@@ -816,6 +817,8 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
         const uint32_t m = (1u << pd.bits) - 1u;
         uint32_t s = p < 4 ? s0[p < 4 ? p : 0] : hash32((key >> pd.shift) & pd.mask, pd.bits);
         uint64_t v = p < 4 ? v0[p < 4 ? p : 0] : ptab[pd.off + s];
+        uint64_t vn = p < 4 ? v1[p < 4 ? p : 0] : KEY_EMPTY;
+        bool have_next = p < 4;
         for (;;) {
             if (v == KEY_EMPTY) break;
             uint64_t x = (v >> ib) ^ key;
@@ -829,7 +832,8 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
                 if (!dup) t.offer(ham2(x & keep) + nforced, (uint32_t)(v & imask));
             }
             s = (s + 1) & m;
-            v = ptab[pd.off + s];
+            if (have_next) { v = vn; have_next = false; }
+            else v = ptab[pd.off + s];
         }
     }
 }
