@@ -439,28 +439,41 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
         else acc_add(&acc.counts[idx], 1ull);
     };
 
+    // Software pipeline: the rows of the workgroup's NEXT tile are requested before the current tile is processed, so
+    // a wave's HBM latency hides under its own anchor search.  The kernel sits at 2 waves/SIMD anyway (LDS: histogram +
+    // rings, two workgroups per CU), so the 10*NW + 1 extra registers cost no occupancy.
+    uint32_t nLO[NW], nHI[NW], nQ[NQW], nl = F2Q_LEN_SKIP;
+    auto request_tile = [&](uint32_t t) {
+        const auto bpn = gp(pb.bases) + (uint64_t)t * pb.wb * F2Q_TILE + tid;
+        const auto qpn = gp(pb.qual) + (uint64_t)t * pb.wq * F2Q_TILE + tid;
+        nl = pb.len ? gp(pb.len)[(uint64_t)t * F2Q_TILE + tid] : pb.rmax;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            nLO[w] = __builtin_nontemporal_load(bpn + (uint64_t)w * F2Q_TILE);
+            nHI[w] = __builtin_nontemporal_load(bpn + (uint64_t)(NW + w) * F2Q_TILE);
+        }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) nQ[i] = __builtin_nontemporal_load(qpn + (uint64_t)i * F2Q_TILE);   // planar tiles always hold 8*NW rows
+    };
+    if (blockIdx.x < pb.n_tiles) request_tile(blockIdx.x);
     for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
-        const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + tid;
-        const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + tid;
 #ifdef F2Q_STAMP
         __builtin_amdgcn_sched_barrier(0); t0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-        const uint32_t l = pb.len ? gp(pb.len)[(uint64_t)tile * F2Q_TILE + tid] : pb.rmax;
-        uint32_t LO[NW], HI[NW];
+        const uint32_t l = nl;
+        uint32_t LO[NW], HI[NW], Q[NQW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            LO[w] = __builtin_nontemporal_load(bp + (uint64_t)w * F2Q_TILE);
-            HI[w] = __builtin_nontemporal_load(bp + (uint64_t)(NW + w) * F2Q_TILE);
-        }
+        for (int w = 0; w < NW; w++) { LO[w] = nLO[w]; HI[w] = nHI[w]; }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) Q[i] = nQ[i];
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + gridDim.x < pb.n_tiles) request_tile(tile + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
         // quality words -> per-base fail vectors.  All 8*NW loads are issued together (one memory round trip);
         // the scheduling barrier keeps the compiler from stretching their live ranges into the anchor search.
         uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW], FLG[NW];
         const bool flagged = (l != F2Q_LEN_SKIP) && (l & F2Q_LEN_FLAG);
         {
-            uint32_t Q[NQW];
-#pragma unroll
-            for (int i = 0; i < NQW; i++)
-                Q[i] = __builtin_nontemporal_load(qp + (uint64_t)i * F2Q_TILE);      // planar tiles always hold 8*NW quality rows
 #pragma unroll
             for (int cw = 0; cw < NW; cw++) {
                 uint32_t q8[8];
