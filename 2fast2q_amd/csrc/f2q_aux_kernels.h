@@ -1,0 +1,224 @@
+// f2q_aux_kernels.h -- kernels around the counting path (included by f2q_lib.hip only): Extract+Count table
+// growth, the synthetic workload generator, and the device-side FASTQ ingest (framing + classification + packing).
+#pragma once
+
+// re-insert every entry of `old` into `nw` (table growth)
+__global__ void k_ec_rehash(EcDev old, unsigned long long n_old, EcDev nw)
+{
+    unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_old) return;
+    const uint32_t len = old.ent_len[e];
+    const uint32_t *src = old.arena + old.ent_off[e];
+    const int nwords = (int)((len + 3) >> 2);
+    // same hash as key_hash() over the stored bytes
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+    for (uint32_t k = 0; k < len; k++) { h ^= (src[k >> 2] >> (8 * (k & 3))) & 0xFFu; h *= 1099511628211ull; }
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const unsigned long long fp = (h >> 32) & 0xFFFFFFFFull;
+    // keys are distinct, so plain claim-by-CAS of an empty slot is enough
+    unsigned long long ne = atomicAdd(&nw.ctr[0], 1ull);
+    unsigned long long off = atomicAdd(&nw.ctr[1], (unsigned long long)nwords);
+    for (int w = 0; w < nwords; w++) nw.arena[off + w] = src[w];
+    nw.ent_off[ne] = off; nw.ent_len[ne] = len;
+    nw.ent_count[ne] = old.ent_count[e]; nw.ent_first[ne] = old.ent_first[e];
+    uint32_t s = (uint32_t)h & nw.mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&nw.slots[s], 0ull, (fp << 32) | (ne + 1ull));
+        if (prev == 0ull) break;
+        s = (s + 1) & nw.mask;
+    }
+}
+
+// move every key of the old single-word table into the new one (keys are distinct)
+__global__ void k_ec64_rehash(EcDev old, EcDev nw)
+{
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > old.k64_mask) return;
+    const unsigned long long k = old.k64_slots[i];
+    if (k == KEY_EMPTY) return;
+    uint32_t s = hash32(k ^ (k >> 29), 32) & nw.k64_mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS(&nw.k64_slots[s], KEY_EMPTY, k);
+        if (prev == KEY_EMPTY) break;
+        s = (s + 1) & nw.k64_mask;
+    }
+    nw.k64_count[s] = old.k64_count[i]; nw.k64_first[s] = old.k64_first[i];
+    atomicAdd(&nw.ctr[3], 1ull);
+}
+
+// ---- synthetic workload, device side ----------------------------------------------------------
+struct SynthOut {
+    // packed planes (may be null when everything goes to the general path)
+    uint32_t *bases, *qual; uint16_t *len; uint32_t wb, wq, planar_nw;
+    // general records: fixed stride R for seq and R for quality
+    uint8_t *raw; unsigned long long *off; uint32_t *glen, *gqlen, *gindex;
+    unsigned long long *g_count; unsigned long long g_cap;
+    int all_general;           // 1: every read is written as a raw record
+    int inband_n;              // 1: an 'N' inside the window is flagged in place instead of taking the general path
+};
+
+__global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *__restrict__ guide_keys, SynthOut o,
+                                                     uint64_t n_slots)
+{
+    const uint64_t slot = (uint64_t)blockIdx.x * F2Q_TILE + threadIdx.x;
+    if (slot >= n_slots) return;
+    const uint64_t tile = slot / F2Q_TILE, lane = slot % F2Q_TILE;
+    if (slot >= s.n_reads) { if (o.len) o.len[slot] = (uint16_t)F2Q_LEN_SKIP; return; }
+    const uint64_t i = s.first_read + slot;
+    SynthRead r = synth_plan(s, i, [&](uint32_t g) { return guide_keys[g]; });
+    const int R = s.read_len;
+    // does the read hold a symbol the packed planes cannot carry?  (only 'N' is ever generated)
+    bool dirty = o.all_general != 0;
+    const int npos = (r.n_pos >= 0 && r.wstart + r.n_pos < R) ? r.wstart + r.n_pos : -1;
+    if (!dirty && npos >= 0 && !o.inband_n) dirty = true;
+    if (dirty) {
+        if (o.len) o.len[slot] = (uint16_t)F2Q_LEN_SKIP;
+        unsigned long long g = atomicAdd(o.g_count, 1ull);
+        if (g >= o.g_cap) return;                      // host checks g_count against g_cap afterwards
+        uint8_t *dst = o.raw + g * (unsigned long long)(2 * R);
+        uint64_t fw = 0;
+        for (int p = 0; p < R; p++) {
+            if ((p & 31) == 0) fw = rnd(s.seed, i, F_FLANK0 + (p >> 5));
+            dst[p] = synth_base(s, r, p, fw);
+            dst[R + p] = (p == r.qpos) ? r.qchar : (uint8_t)'I';
+        }
+        o.off[g] = g * (unsigned long long)(2 * R);
+        o.glen[g] = (uint32_t)R; o.gqlen[g] = (uint32_t)R; o.gindex[g] = (uint32_t)slot;
+        // the packed slot stays zero-filled and is skipped through the len plane
+        return;
+    }
+    if (o.len) o.len[slot] = (uint16_t)((uint32_t)R | (npos >= 0 ? F2Q_LEN_FLAG : 0u));
+    uint32_t *bp = o.bases + (tile * o.wb) * F2Q_TILE + lane;
+    uint32_t *qp = o.qual + (tile * o.wq) * F2Q_TILE + lane;
+    uint64_t fw = 0;
+    uint32_t bw = 0, qw = 0, lw = 0, hw = 0;
+    for (int p = 0; p < R; p++) {
+        if ((p & 31) == 0) fw = rnd(s.seed, i, F_FLANK0 + (p >> 5));
+        uint8_t c = synth_base(s, r, p, fw);
+        uint32_t code = base_code(c); if (code > 3u) code = 0;
+        qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * (p & 3));
+        if ((p & 3) == 3 || p == R - 1) { qp[(uint64_t)(p >> 2) * F2Q_TILE] = qw; qw = 0; }
+        if (o.planar_nw) {                       // anchored runs: bit-planes, 32 bases per word
+            lw |= (code & 1u) << (p & 31); hw |= (code >> 1) << (p & 31);
+            if ((p & 31) == 31 || p == R - 1) {
+                bp[(uint64_t)(p >> 5) * F2Q_TILE] = lw; bp[(uint64_t)(o.planar_nw + (p >> 5)) * F2Q_TILE] = hw;
+                lw = 0; hw = 0;
+            }
+        } else {
+            bw |= code << (2 * (p & 15));
+            if ((p & 15) == 15 || p == R - 1) { bp[(uint64_t)(p >> 4) * F2Q_TILE] = bw; bw = 0; }
+        }
+    }
+}
+
+// ---- device-side ingest: FASTQ text -> record table -> tiles ------------------------------------------
+// The host only moves the text to the device.  k_nl_count / k_line_starts find every line start (two passes
+// around a device-wide prefix sum), k_classify applies fastq_parser's framing (4 rstrip()-ed lines per record,
+// fast2q.py:324-328) and decides per read whether the tile planes can carry it, k_pack lays clean reads
+// into tiles and lists the others as raw records that point into the text itself.
+#define F2Q_NL_CHUNK 4096u          // bytes per workgroup: 256 threads x 16 bytes
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t F2Q_GLOBAL *text, uint64_t pos, uint64_t nbytes)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    v4 v = *(const v4 F2Q_GLOBAL *)(text + pos);                  // the buffer is padded to a chunk multiple
+    uint32_t m = 0;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (((w[k] >> (8 * b)) & 0xFFu) == (uint32_t)'\n' && pos + (uint64_t)(4 * k + b) < nbytes) m |= 1u << (4 * k + b);
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t *text, uint64_t nbytes, uint32_t *chunk_counts)
+{
+    typedef hipcub::BlockReduce<uint32_t, 256> BR;
+    __shared__ typename BR::TempStorage tmp;
+    const uint64_t pos = (uint64_t)blockIdx.x * F2Q_NL_CHUNK + threadIdx.x * 16u;
+    const uint32_t c = __popc(nl_mask16(gp(text), pos, nbytes));
+    const uint32_t tot = BR(tmp).Sum(c);
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = tot;
+}
+
+// line_start[k] = offset of line k; line_start[n_newlines + 1] = nbytes + 1 (end sentinel for an unterminated last line)
+__global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint64_t nbytes, const uint32_t *chunk_prefix,
+                                                      uint32_t *line_start)
+{
+    typedef hipcub::BlockScan<uint32_t, 256> BS;
+    __shared__ typename BS::TempStorage tmp;
+    const uint64_t pos = (uint64_t)blockIdx.x * F2Q_NL_CHUNK + threadIdx.x * 16u;
+    uint32_t m = nl_mask16(gp(text), pos, nbytes);
+    uint32_t before = 0;
+    BS(tmp).ExclusiveSum((uint32_t)__popc(m), before);
+    uint32_t k = chunk_prefix[blockIdx.x] + before + 1u;
+    while (m) { const uint32_t b = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u; gpw(line_start)[k++] = (uint32_t)(pos + b + 1u); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) gpw(line_start)[0] = 0u;
+}
+
+struct IngestDev {
+    const uint8_t *text; const uint32_t *line_start; uint32_t n_records;
+    uint32_t *r_off, *r_len, *r_qoff, *r_qlen;   // per record: sequence / quality line (offset, rstrip()-ed length)
+    uint32_t *clean;                             // per record: 1 = goes into the tiles
+    uint32_t *meta;                              // [0] longest packed length among clean reads
+};
+
+__device__ __forceinline__ uint32_t rstrip_dev(gbytes p, uint32_t n)
+{
+    while (n > 0) {
+        const uint8_t c = p[n - 1];
+        if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c) n--; else break;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_classify(IngestDev d, PackPlan pl)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= d.n_records) return;
+    const auto ls = gp(d.line_start);
+    const uint32_t s0 = ls[4u * r + 1u], e0 = ls[4u * r + 2u] - 1u, s1 = ls[4u * r + 3u], e1 = ls[4u * r + 4u] - 1u;
+    RecT<gbytes> rec;
+    rec.seq = gp(d.text) + s0; rec.qual = gp(d.text) + s1;
+    rec.len = rstrip_dev(rec.seq, e0 - s0); rec.qlen = rstrip_dev(rec.qual, e1 - s1);
+    gpw(d.r_off)[r] = s0; gpw(d.r_len)[r] = rec.len; gpw(d.r_qoff)[r] = s1; gpw(d.r_qlen)[r] = rec.qlen;
+    const bool clean = read_is_clean(pl, rec);
+    gpw(d.clean)[r] = clean ? 1u : 0u;
+    if (clean) atomicMax(&d.meta[0], packed_len(pl, rec));
+}
+
+struct DevSink {
+    uint32_t F2Q_GLOBAL *bp; uint32_t F2Q_GLOBAL *qp; uint16_t F2Q_GLOBAL *lp;
+    __device__ void base(uint32_t w, uint32_t v) { bp[(uint64_t)w * F2Q_TILE] = v; }
+    __device__ void qual(uint32_t w, uint32_t v) { qp[(uint64_t)w * F2Q_TILE] = v; }
+    __device__ void len(uint32_t v) { *lp = (uint16_t)v; }
+};
+
+struct PackOut {
+    uint32_t *bases, *qual; uint16_t *len; uint32_t *c_index; uint32_t wb, wq, planar_nw;
+    unsigned long long *g_off, *g_qoff; uint32_t *g_len, *g_qlen, *g_index;
+};
+
+// clean_before = exclusive prefix sum of IngestDev::clean
+__global__ __launch_bounds__(256) void k_pack(IngestDev d, PackPlan pl, const uint32_t *clean_before, PackOut o)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= d.n_records) return;
+    const uint32_t slot = gp(clean_before)[r];
+    RecT<gbytes> rec;
+    rec.seq = gp(d.text) + gp(d.r_off)[r]; rec.qual = gp(d.text) + gp(d.r_qoff)[r];
+    rec.len = gp(d.r_len)[r]; rec.qlen = gp(d.r_qlen)[r];
+    if (gp(d.clean)[r]) {
+        const uint64_t tile = slot / F2Q_TILE, lane = slot % F2Q_TILE;
+        DevSink sink{gpw(o.bases) + tile * o.wb * F2Q_TILE + lane, gpw(o.qual) + tile * o.wq * F2Q_TILE + lane,
+                     gpw(o.len) + tile * F2Q_TILE + lane};
+        pack_read(pl, rec, o.planar_nw, sink);
+        if (o.c_index) gpw(o.c_index)[slot] = r;
+    } else {
+        const uint32_t g = r - slot;
+        gpw(o.g_off)[g] = gp(d.r_off)[r]; gpw(o.g_qoff)[g] = gp(d.r_qoff)[r];
+        gpw(o.g_len)[g] = rec.len; gpw(o.g_qlen)[g] = rec.qlen; gpw(o.g_index)[g] = r;
+    }
+}
+

@@ -1,0 +1,678 @@
+// f2q_count_kernels.h -- the counting kernels of libf2q_hip.so (included by f2q_lib.hip only).
+//   k_count_fixed4    fixed-offset Counter mode, 4 reads per lane on interleaved tiles (the bench kernel)
+//   k_extract_fixed4  fixed-window Extract+Count
+//   k_count_anchor    --us/--ds runs on bit-plane tiles (Counter and Extract+Count)
+//   k_count_fixed     one read per lane (wide tables / A-B runs)
+//   k_count_general   byte-exact routine on raw records
+//   k_hist_ranges, k_reduce_slabs   histogram / counter reduction
+#pragma once
+
+// ===============================================================================================
+// kernels
+// ===============================================================================================
+#define F2Q_HIST_MAX 24576u     // features whose u32 histogram fits the workgroup's LDS budget (96 KiB)
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Workgroup-level sum of the 5 reference counters: same-address global atomics serialise in L2
+// (20k of them cost ~0.2 ms per launch), so a workgroup issues at most one per counter -- or none
+// when it can leave its sums in a slab row for k_reduce_slabs.
+__device__ __forceinline__ void flush_stats(const Accum &acc, unsigned long long st[5], unsigned long long *lds8,
+                                            unsigned long long *slab_row)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < 8) lds8[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = 0; k < 5; k++) {
+        unsigned long long v = wave_sum(st[k]);
+        if (lane == 0 && v) atomicAdd(&lds8[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        unsigned long long v = lds8[threadIdx.x];
+        if (slab_row) gpw(slab_row)[threadIdx.x] = v;
+        else if (v) acc_add(&acc.stats[threadIdx.x], v);
+    }
+}
+
+// Fast path, fixed offset.  Persistent workgroups stride over the tiles.  USE_LDS: per-workgroup
+// u32 histogram in LDS, flushed once with 64-bit global atomics.
+template <bool USE_LDS>
+__global__ __launch_bounds__(F2Q_TILE) void k_count_fixed(const RunDev *__restrict__ runp,
+                                                            const LibDev *__restrict__ libp, PackedBlock pb,
+                                                            Accum acc)
+{
+    extern __shared__ uint32_t hist[];
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features;
+    if (USE_LDS) {
+        for (uint32_t i = threadIdx.x; i < nf; i += F2Q_TILE) hist[i] = 0;
+        __syncthreads();
+    }
+    unsigned long long st1 = 0, st2 = 0, st3 = 0, st4 = 0, st0 = 0;
+    for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
+        uint32_t idx = 0;
+        int res = fixed_lane(run, lib, pb, tile, threadIdx.x, idx);
+        if (res == 1 || res == 2) {
+            if (USE_LDS) atomicAdd(&hist[idx], 1u);
+            else acc_add(&acc.counts[idx], 1ull);
+        }
+        st0 += (res != 0); st1 += (res == 1); st2 += (res == 2); st3 += (res == 3); st4 += (res == 4);
+    }
+    __shared__ unsigned long long st_lds[8];
+    unsigned long long stv[5] = {st0, st1, st2, st3, st4};
+    flush_stats(acc, stv, st_lds, nullptr);
+    if (USE_LDS) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nf; i += F2Q_TILE) {
+            uint32_t c = hist[i];
+            if (c) acc_add(&acc.counts[i], (unsigned long long)c);
+        }
+    }
+}
+
+// ---- fast path v2 -----------------------------------------------------------------------------------
+// One wave per 256-read tile, lane l owns reads 4l..4l+3: every tile row is one 16-byte load per lane
+// (1 KiB per wave instruction).  Exact probes hit the packed table (key|index in one u64, two slots in
+// flight per round, four reads in flight per lane).  Reads whose exact probe misses are not searched in
+// place -- that would run the pigeonhole chains with ~15 % of the lanes active -- but pushed into an LDS
+// ring; once a workgroup's ring holds a full workgroup of keys they are searched one per lane.
+#define F2Q_V2_THREADS 512
+#define F2Q_V2_WAVES (F2Q_V2_THREADS / 64)
+#define F2Q_V2_QCAP 320u      // entries per wave ring: < 64 left over + <= 256 pushed per tile
+
+template <bool NT>
+__device__ __forceinline__ U4 ld_u4(const uint32_t F2Q_GLOBAL *p)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 F2Q_GLOBAL *q = (const v4 F2Q_GLOBAL *)p;
+    v4 v = NT ? __builtin_nontemporal_load(q) : *q;      // NT: stream once, keep L2 for the tables
+    return U4{v.x, v.y, v.z, v.w};
+}
+
+__device__ __noinline__ int slow_read(const RunDev *run, const LibDev *lib, const PackedBlock *pb, uint32_t tile,
+                                      uint32_t slot, uint32_t *idx)
+{
+    return fixed_lane(*run, *lib, *pb, tile, slot, *idx);
+}
+
+// NQ / NB: number of quality / base rows under the window when known at compile time (the common
+// geometries get their own instantiation so that all row loads sit in one basic block and issue
+// back to back); 0 = run-time geometry, rows beyond the window are clamped re-loads of the last one.
+template <bool USE_LDS, int NQ, int NB>
+// launch bound 4 waves/SIMD = two 512-thread workgroups per CU
+__global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev *__restrict__ runp,
+                                                                  const LibDev *__restrict__ libp, PackedBlock pb,
+                                                                  Accum acc)
+{
+    extern __shared__ unsigned long long smem64[];
+    // one ring of keys per wave: pushes and drains are wave-synchronous, so the tile loop has no barrier
+    unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;                 // keys
+    uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + (threadIdx.x >> 6) * F2Q_V2_QCAP;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + F2Q_V2_WAVES * F2Q_V2_QCAP;  // USE_LDS
+    // !USE_LDS (library too large for an LDS histogram): the same region holds the read slot of every ring entry
+    uint32_t *qslot = hist + (threadIdx.x >> 6) * F2Q_V2_QCAP;
+
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (USE_LDS) for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) hist[i] = 0;
+    __syncthreads();
+    uint32_t q_head = 0, q_tail = 0;          // the ring belongs to this wave alone: head and tail live in (uniform) registers
+    const FixedGeom g = fixed_geom(run);
+    const int need = g.st + g.L;
+    const bool do_near = run.miss > 0;
+    const PackedPiece ex = lib.pk.exact;
+    const uint32_t ib = lib.pk.ib, exm = (1u << ex.bits) - 1u;
+    const uint64_t imask = (1ull << ib) - 1ull;
+    const auto ptab = gp(lib.ptab);
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+#ifdef F2Q_STAMP
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t0_ = 0, t1_;
+#define STAMP4(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP4(i) do {} while (0)
+#endif
+
+    // a hit: LDS histogram, or (large library) the feature index is stored at the read's slot for k_hist_ranges
+    auto count_hit = [&](uint32_t idx, uint64_t slot) {
+        if (USE_LDS) atomicAdd(&hist[idx], 1u);
+        else gpw(acc.hit_buf)[slot] = idx;
+    };
+
+    for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
+        const uint32_t tile = base + wave;
+#ifdef F2Q_STAMP
+        __builtin_amdgcn_sched_barrier(0); t0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+        int res[4] = {R_SKIP, R_SKIP, R_SKIP, R_SKIP};
+        uint64_t key[4] = {0, 0, 0, 0};
+        uint32_t forced[4] = {0, 0, 0, 0};
+        if (tile < pb.n_tiles) {
+            constexpr int QR = NQ ? NQ : F2Q_MAXQROWS, BR = NB ? NB : F2Q_MAXBROWS;
+            constexpr bool NT = true;                    // tile rows are streamed once: keep L2 for the tables
+            U4 brow[BR], qrow[QR];
+            const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane;
+            const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane;
+            // every load of the tile is issued before anything is consumed
+#pragma unroll
+            for (int r = 0; r < BR; r++) {
+                uint32_t row = (uint32_t)g.bw0 + (uint32_t)(NB ? r : (r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0)));
+                row = row < pb.wb ? row : pb.wb - 1u;       // reads shorter than the window: stay inside the tile
+                brow[r] = ld_u4<NT>(bp + (uint64_t)row * F2Q_TILE);
+            }
+            if (NQ || g.add_hi) {                        // --ph <= 1: no quality row is needed at all
+#pragma unroll
+                for (int r = 0; r < QR; r++) {
+                    uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0)));
+                    row = row < pb.wq ? row : pb.wq - 1u;
+                    qrow[r] = ld_u4<NT>(qp + (uint64_t)row * F2Q_TILE);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < QR; r++) qrow[r] = U4{0, 0, 0, 0};
+            }
+            uint32_t len01 = 0, len23 = 0;
+            if (pb.len) {
+                typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+                v2 lv = *(const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)tile * F2Q_TILE + 4u * lane);
+                len01 = lv.x; len23 = lv.y;
+            }
+            uint32_t bad[4] = {0, 0, 0, 0};
+            if (g.add_hi) {
+#pragma unroll
+                for (int r = 0; r < QR; r++)
+                    if (NQ || r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+                const bool have_q = NQ || g.add_hi;            // the flag bits travel in the quality rows
+                if (l == F2Q_LEN_SKIP) res[j] = R_SKIP;
+                else if ((int)(l & 0x7FFFu) < need || g.L < 1 || ((l & F2Q_LEN_FLAG) && !have_q)) res[j] = R_SLOW;
+                else if (bad[j]) res[j] = R_QFAIL;
+                else {
+                    res[j] = R_NEAR; key[j] = fixed4_key(g, brow, j);
+                    if (l & F2Q_LEN_FLAG) {                    // non-ACGT symbols in the window (rare)
+                        forced[j] = fixed4_flags(g, qrow, j);
+                        if (forced[j]) res[j] = (!do_near || __popc(forced[j]) > run.miss) ? R_NONALIGNED : R_FORCED;
+                    }
+                }
+            }
+            STAMP4(0);                              // row loads, Phred, keys
+            // exact probes: up to 4 reads x 2 slots in flight per lane
+            uint32_t s[4]; bool pend[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pend[j] = (res[j] == R_NEAR); s[j] = hash32(key[j], ex.bits); }
+            while (pend[0] | pend[1] | pend[2] | pend[3]) {
+                uint64_t v0[4], v1[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (pend[j]) { v0[j] = ptab[ex.off + s[j]]; v1[j] = ptab[ex.off + ((s[j] + 1u) & exm)]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!pend[j]) continue;
+                    if (v0[j] == KEY_EMPTY) pend[j] = false;
+                    else if ((v0[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v0[j] & imask), (uint64_t)tile * F2Q_TILE + 4u * lane + j); }
+                    else if (v1[j] == KEY_EMPTY) pend[j] = false;
+                    else if ((v1[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v1[j] & imask), (uint64_t)tile * F2Q_TILE + 4u * lane + j); }
+                    else s[j] = (s[j] + 2u) & exm;
+                }
+            }
+            STAMP4(1);                              // exact probes
+            uint32_t npush = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (res[j] == R_SLOW) {                    // clipped window / odd geometry: the one-read routine
+                    uint32_t idx = 0;
+                    int r1 = slow_read(runp, libp, &pb, tile, 4u * lane + (uint32_t)j, &idx);
+                    if (r1 == 1 || r1 == 2) count_hit(idx, (uint64_t)tile * F2Q_TILE + 4u * lane + j);
+                    res[j] = r1;
+                } else if (res[j] == R_NEAR) {
+                    if (do_near) npush++; else res[j] = R_NONALIGNED;
+                } else if (res[j] == R_FORCED) npush++;
+                st0 += (res[j] != R_SKIP); st1 += (res[j] == R_PERFECT); st2 += (res[j] == R_IMPERFECT);
+                st3 += (res[j] == R_NONALIGNED); st4 += (res[j] == R_QFAIL);
+            }
+            {
+                // ring slots by a wave prefix sum of npush (0..4) over three ballots -- no LDS atomics
+                const unsigned long long b0 = __ballot(npush & 1u), b1 = __ballot(npush & 2u), b2 = __ballot(npush & 4u);
+                uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))
+                              + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u))
+                              + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+                q_tail += (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (res[j] == R_NEAR || res[j] == R_FORCED) {
+                        queue[at % F2Q_V2_QCAP] = key[j]; qforced[at % F2Q_V2_QCAP] = forced[j];
+                        if (!USE_LDS) qslot[at % F2Q_V2_QCAP] = tile * F2Q_TILE + 4u * lane + (uint32_t)j;   // slot inside the block (< 2^32)
+                        at++;
+                    }
+            }
+        }
+        STAMP4(2);                                  // histogram, slow reads, ring push
+        if (do_near) {
+            // LDS operations of one wave complete in order; the fence keeps the compiler from moving the reads up
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t tail = q_tail;
+            while (tail - q_head >= 64u) {
+                uint32_t idx = 0;
+                int r = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], idx);
+                if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx, USE_LDS ? 0u : qslot[(q_head + lane) % F2Q_V2_QCAP]); st2++; } else st3++;
+                q_head += 64u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        STAMP4(3);                                  // ring drain
+    }
+    if (do_near) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t tail = q_tail;
+        if (lane < tail - q_head) {
+            uint32_t idx = 0;
+            int r = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_V2_QCAP], qforced[(q_head + lane) % F2Q_V2_QCAP], idx);
+            if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx, USE_LDS ? 0u : qslot[(q_head + lane) % F2Q_V2_QCAP]); st2++; } else st3++;
+        }
+    }
+#ifdef F2Q_STAMP
+    if (lane == 0 && acc.stamp) for (int i = 0; i < 4; i++) atomicAdd(&acc.stamp[i], tp[i]);
+#endif
+    __shared__ unsigned long long st_lds[8];
+    unsigned long long stv[5] = {st0, st1, st2, st3, st4};
+    flush_stats(acc, stv, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
+    if (USE_LDS) {
+        // the workgroup's histogram leaves as one coalesced slab row; k_reduce_slabs sums the rows
+        __syncthreads();
+        auto row = gpw(acc.slab) + (uint64_t)blockIdx.x * nf;
+        for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) row[i] = hist[i];
+    }
+}
+
+// Extract+Count with a fixed window (--mo EC --st/--l): same tile walk and Phred test as k_count_fixed4, but every
+// passing window (clipped to the read, possibly empty) is a key of the single-word device table -- no library.
+__global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev *__restrict__ runp, EcDev ec, PackedBlock pb,
+                                                                    Accum acc, uint64_t read_base)
+{
+    const RunDev &run = *runp;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const FixedGeom g = fixed_geom(run);
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
+        const uint32_t tile = base + wave;
+        if (tile >= pb.n_tiles) continue;
+        U4 brow[F2Q_MAXBROWS], qrow[F2Q_MAXQROWS];
+        const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane;
+        const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane;
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXBROWS; r++) {
+            uint32_t row = (uint32_t)g.bw0 + (uint32_t)(r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
+            row = row < pb.wb ? row : pb.wb - 1u;
+            brow[r] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
+        }
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXQROWS; r++) {
+            const uint32_t want = (uint32_t)g.qw0 + (uint32_t)(r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
+            const uint32_t row = want < pb.wq ? want : pb.wq - 1u;
+            // a row past the tile's last one holds no byte of any read of the block: it must test as "nothing fails"
+            qrow[r] = (g.add_hi && want < pb.wq) ? ld_u4<true>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
+        }
+        uint32_t len01 = 0, len23 = 0;
+        if (pb.len) {
+            typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+            v2 lv = *(const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)tile * F2Q_TILE + 4u * lane);
+            len01 = lv.x; len23 = lv.y;
+        }
+        uint32_t bad[4] = {0, 0, 0, 0};
+        if (g.add_hi) {
+#pragma unroll
+            for (int r = 0; r < F2Q_MAXQROWS; r++)
+                if (r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+            if (l == F2Q_LEN_SKIP) continue;
+            st[0]++;
+            // bytes past the end of a short read are stored as 0 and never fail, so bad[] already is the clipped test
+            if (bad[j]) { st[4]++; continue; }
+            const int rl = (int)(l & 0x7FFFu);
+            int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;             // Python slice clipping (:354)
+            if (L < 0) L = 0;
+            const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
+            const uint64_t slot = (uint64_t)tile * F2Q_TILE + 4u * lane + (uint32_t)j;
+            ec64_insert(ec, key, L, read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
+            st[1]++;
+        }
+    }
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
+}
+
+// ---- fast path, anchored ------------------------------------------------------------------------------
+// One lane = one read of a planar tile (bit-planes, see f2q_device.h).  Every byte of every read is
+// needed here (the anchors can sit anywhere, the Phred tests follow them), so this is the kernel that
+// streams the full 188 B/read: 2*NW base words + 8*NW quality words + the length per lane, all as
+// coalesced 256-byte rows.  Counter mode: exact probe, misses queued per wave for the pigeonhole
+// search, LDS histogram.  Extract+Count mode: single-word insert into the device table.
+#define F2Q_AN_THREADS 256
+#define F2Q_AN_WAVES (F2Q_AN_THREADS / 64)
+#define F2Q_AN_QCAP 512u          // entries per wave ring (power of two: the ring index is a mask, not a multiply)
+
+// odd geometry (negative-index slices, windows the 2-bit tables cannot hold): the byte-exact general routine
+// on a private copy of the read, rebuilt from the tile in memory so that the caller keeps nothing live for it
+__device__ __noinline__ void anchor_slow(const RunDev *run, const LibDev *lib, const EcDev *ec, const Accum *acc,
+                                         const PackedBlock *pb, uint32_t tile, uint32_t slot, int r,
+                                         unsigned long long read_index, unsigned long long *st)
+{
+    uint8_t seq[F2Q_ANCHOR_MAXLEN], qual[F2Q_ANCHOR_MAXLEN];
+    const uint32_t nw = pb->planar_nw;
+    const auto bp = gp(pb->bases) + (uint64_t)tile * pb->wb * F2Q_TILE + slot;
+    const auto qp = gp(pb->qual) + (uint64_t)tile * pb->wq * F2Q_TILE + slot;
+    if (r > F2Q_ANCHOR_MAXLEN) r = F2Q_ANCHOR_MAXLEN;
+    for (int i = 0; i < r; i++) {
+        const uint32_t lo = bp[(uint64_t)(i >> 5) * F2Q_TILE], hi = bp[(uint64_t)(nw + (i >> 5)) * F2Q_TILE];
+        seq[i] = (uint8_t)"ACGT"[((lo >> (i & 31)) & 1u) | (((hi >> (i & 31)) & 1u) << 1)];
+        qual[i] = (uint8_t)((qp[(uint64_t)(i >> 2) * F2Q_TILE] >> (8 * (i & 3))) & 0xFFu);
+        if (qual[i] & 0x80u) { seq[i] = (uint8_t)'N'; qual[i] &= 0x7Fu; }      // flagged: a symbol that equals nothing
+    }
+    general_read<const uint8_t *>(*run, *lib, *ec, *acc, seq, r, qual, r, read_index, st);
+}
+
+// SAMEQ: --qsu == --qsd == --ph (the default), one fail vector serves all three Phred tests
+template <int NW, int KB, bool EC, bool USE_LDS, bool SAMEQ>
+__global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *__restrict__ runp,
+                                                                  const LibDev *__restrict__ libp, EcDev ec,
+                                                                  PackedBlock pb, Accum acc, uint64_t read_base)
+{
+    constexpr int NQW = 8 * NW;
+    extern __shared__ unsigned long long smem64[];
+    unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_AN_QCAP;
+    uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_AN_QCAP) + (threadIdx.x >> 6) * F2Q_AN_QCAP;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_AN_WAVES * F2Q_AN_QCAP) + F2Q_AN_WAVES * F2Q_AN_QCAP;
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (USE_LDS && !EC) for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) hist[i] = 0;
+    __syncthreads();
+    uint32_t q_head = 0, q_tail = 0;          // this wave's ring: head and tail in (uniform) registers
+    const bool do_near = run.miss > 0;
+    const int pk_len = (int)lib.pk.len;
+    const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+#ifdef F2Q_STAMP
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t0_, t1_;
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+    auto count_hit = [&](uint32_t idx) {
+        if (USE_LDS) atomicAdd(&hist[idx], 1u);
+        else acc_add(&acc.counts[idx], 1ull);
+    };
+
+    // Software pipeline: the rows of the workgroup's NEXT tile are requested before the current tile is processed, so
+    // a wave's HBM latency hides under its own anchor search.  The kernel sits at 2 waves/SIMD anyway (LDS: histogram +
+    // rings, two workgroups per CU), so the 10*NW + 1 extra registers cost no occupancy.
+    uint32_t nLO[NW], nHI[NW], nQ[NQW], nl = F2Q_LEN_SKIP;
+    auto request_tile = [&](uint32_t t) {
+        const auto bpn = gp(pb.bases) + (uint64_t)t * pb.wb * F2Q_TILE + tid;
+        const auto qpn = gp(pb.qual) + (uint64_t)t * pb.wq * F2Q_TILE + tid;
+        nl = pb.len ? gp(pb.len)[(uint64_t)t * F2Q_TILE + tid] : pb.rmax;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            nLO[w] = __builtin_nontemporal_load(bpn + (uint64_t)w * F2Q_TILE);
+            nHI[w] = __builtin_nontemporal_load(bpn + (uint64_t)(NW + w) * F2Q_TILE);
+        }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) nQ[i] = __builtin_nontemporal_load(qpn + (uint64_t)i * F2Q_TILE);   // planar tiles always hold 8*NW rows
+    };
+    if (blockIdx.x < pb.n_tiles) request_tile(blockIdx.x);
+    for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
+#ifdef F2Q_STAMP
+        __builtin_amdgcn_sched_barrier(0); t0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+        const uint32_t l = nl;
+        uint32_t LO[NW], HI[NW], Q[NQW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) { LO[w] = nLO[w]; HI[w] = nHI[w]; }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) Q[i] = nQ[i];
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + gridDim.x < pb.n_tiles) request_tile(tile + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        // quality words -> per-base fail vectors.  All 8*NW loads are issued together (one memory round trip);
+        // the scheduling barrier keeps the compiler from stretching their live ranges into the anchor search.
+        uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW], FLG[NW];
+        const bool flagged = (l != F2Q_LEN_SKIP) && (l & F2Q_LEN_FLAG);
+        {
+#pragma unroll
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q8[i] = Q[8 * cw + i];
+                FW[cw] = fail_word8(q8, ah_w);
+                if (!SAMEQ) { FU[cw] = fail_word8(q8, ah_u); FD[cw] = fail_word8(q8, ah_d); }
+                FLG[cw] = flagged ? flag_word8(q8) : 0u;          // non-ACGT symbols (rare reads)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(0);                                   // loads + fail vectors
+        bool push = false; uint64_t push_key = 0; uint32_t push_forced = 0;
+        if (l != F2Q_LEN_SKIP) {
+            const int r = (int)(l & 0x7FFFu);
+            const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
+            const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+            AnchorWin aw;
+            if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, LO, HI, FLG, r, FW, FW, FW);
+            else aw = anchor_window<NW, KB, KB>(run, LO, HI, FLG, r, FU, FD, FW);
+            STAMP(1);                               // anchor search + region tests
+            const int L = aw.end - aw.start;
+            if (aw.ok == 0) { st[4]++; st[0]++; }
+            else if (aw.ok == 1 && !EC && (L < 1 || L > F2Q_REG_MAXLEN)) {
+                // Counter mode, all-ACGT library of <= 31-base features (the packed path's precondition): an empty
+                // or longer window passed its Phred test but can equal or approach no feature (:683) -> not aligned
+                st[3]++; st[0]++;
+            } else if (aw.ok == 1 && EC && L > F2Q_EC64_MAXLEN) {
+                // Extract+Count key too long for the single-word table: decode the window and use the byte-string table
+                uint8_t kb[32 * NW];
+#pragma unroll
+                for (int cw = 0; cw < NW; cw++) {
+                    const int off = 32 * cw, n = L - off < 32 ? L - off : 32;
+                    if (n > 0) {
+                        const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
+                        for (int j = 0; j < n; j++) kb[off + j] = (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
+                    }
+                }
+                KeyView kv; kv.seq = kb; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = L; kv.len = L;
+                ec_insert(ec, kv, gi);
+                st[1]++; st[0]++;
+            } else if (aw.ok == 2) {
+                // negative-index slices (down-only anchor near the read start, negative --l): byte-exact routine
+                unsigned long long st2[5] = {0, 0, 0, 0, 0};
+                const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
+                anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st2);
+#pragma unroll
+                for (int k = 0; k < 5; k++) st[k] += st2[k];
+            } else if (flagged && plane_extract<NW>(FLG, aw.start, L) != 0u) {
+                // the window itself holds non-ACGT symbols
+                st[0]++;
+                const uint32_t forced = plane_extract<NW>(FLG, aw.start, L);
+                if (EC) {
+                    // unreachable: Extract+Count keys hold the symbol itself, so the packer never flags reads in EC runs
+                    st[3]++;
+                } else if (!do_near || __popc(forced) > run.miss) st[3]++;
+                else {
+                    const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
+                    if (L == pk_len) { push = true; push_key = key; push_forced = forced; }   // queued with its forced mask
+                    else {
+                        MinTrack t; t.init(run.miss);
+                        lib_near(lib, key, L, spread32(forced), t);       // wide tables, in place (rare)
+                        if (t.cnt == 1) { count_hit(t.idx); st[2]++; } else st[3]++;
+                    }
+                }
+            } else {
+                const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
+                st[0]++;
+                if (EC) { ec64_insert(ec, key, L, gi); st[1]++; }
+                else if (L == pk_len) {
+                    const int e = packed_exact(lib, key);
+                    if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
+                    else if (!do_near) st[3]++;
+                    else { push = true; push_key = key; push_forced = 0u; }
+                } else {
+                    // a window of another length than the packed tables index: wide tables, in place (rare)
+                    const int e = lib_exact(lib, key, L);
+                    if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
+                    else {
+                        MinTrack t; t.init(run.miss);
+                        if (do_near) lib_near(lib, key, L, 0ull, t);
+                        if (t.cnt == 1) { count_hit(t.idx); st[2]++; } else st[3]++;
+                    }
+                }
+            }
+        }
+        if (!EC && do_near) {
+            // ring slot by ballot prefix (no LDS atomic)
+            const unsigned long long pm = __ballot(push);
+            if (push) {
+                const uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                queue[at % F2Q_AN_QCAP] = push_key; qforced[at % F2Q_AN_QCAP] = push_forced;
+            }
+            q_tail += (uint32_t)__popcll(pm);
+        }
+        STAMP(2);                                   // key, probe, insert
+        if (!EC && do_near) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t tail = q_tail;
+            while (tail - q_head >= 64u) {
+                uint32_t idx = 0;
+                int rr = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], idx);
+                if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
+                q_head += 64u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        STAMP(3);                                   // ring drain
+    }
+    if (!EC && do_near) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t tail = q_tail;
+        if (lane < tail - q_head) {
+            uint32_t idx = 0;
+            int rr = packed_near_decide(run, lib, queue[(q_head + lane) % F2Q_AN_QCAP], qforced[(q_head + lane) % F2Q_AN_QCAP], idx);
+            if (rr == R_IMPERFECT || rr == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
+        }
+    }
+#ifdef F2Q_STAMP
+    if (lane == 0 && acc.stamp) for (int i = 0; i < 4; i++) atomicAdd(&acc.stamp[i], tp[i]);
+#endif
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
+    if (USE_LDS && !EC) {
+        __syncthreads();
+        auto row = gpw(acc.slab) + (uint64_t)blockIdx.x * nf;
+        for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) row[i] = hist[i];
+    }
+}
+
+// Large libraries (no per-workgroup LDS histogram of the whole library): the counting kernel leaves the feature index
+// of every read in hit_buf; here workgroup (range, part) histograms the indices of its part that fall into its range
+// of F2Q_HIST_MAX features in LDS and writes that stretch of slab row `part`.  hit_buf is read n_ranges times, from
+// the Infinity Cache when it fits (4 B per read).
+__global__ __launch_bounds__(1024) void k_hist_ranges(const uint32_t *__restrict__ hit_buf, uint64_t n_slots, uint32_t nf,
+                                                       uint32_t n_parts, uint32_t *__restrict__ slab)
+{
+    extern __shared__ uint32_t rh[];
+    const uint32_t range = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
+    const uint32_t f0 = range * F2Q_HIST_MAX, fn = (nf - f0) < F2Q_HIST_MAX ? (nf - f0) : F2Q_HIST_MAX;
+    for (uint32_t i = threadIdx.x; i < fn; i += 1024u) rh[i] = 0;
+    __syncthreads();
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint64_t n4 = n_slots / 4;                       // n_slots is a multiple of the tile size
+    const auto hb = (const v4 F2Q_GLOBAL *)hit_buf;
+    for (uint64_t i = (uint64_t)part * 1024u + threadIdx.x; i < n4; i += (uint64_t)n_parts * 1024u) {
+        const v4 v = hb[i];
+        const uint32_t e[4] = {v.x - f0, v.y - f0, v.z - f0, v.w - f0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (e[k] < fn) atomicAdd(&rh[e[k]], 1u);   // 0xFFFFFFFF - f0 is never < fn
+    }
+    __syncthreads();
+    auto row = (uint32_t F2Q_GLOBAL *)slab + (uint64_t)part * nf + f0;
+    for (uint32_t i = threadIdx.x; i < fn; i += 1024u) row[i] = rh[i];
+}
+
+// counts[f] += sum over workgroups of slab[w][f].  Block = 64 features x 4 row lanes; grid.y splits
+// the rows further so that every thread has ~16 independent loads in flight.
+#define F2Q_RED_SPLIT 8u
+__global__ __launch_bounds__(256) void k_reduce_slabs(const uint32_t *__restrict__ slab, uint32_t n_rows, uint32_t nf,
+                                                       unsigned long long *__restrict__ counts,
+                                                       const unsigned long long *__restrict__ stat_slab, uint32_t n_stat_rows,
+                                                       unsigned long long *__restrict__ stats)
+{
+    __shared__ unsigned long long part[256];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && stat_slab) {          // the 5 reference counters: rows of 8
+        const uint32_t k = threadIdx.x & 7u, sub = threadIdx.x >> 3;   // 32 row lanes x 8 columns
+        unsigned long long sv = 0;
+        if (k < 5) for (uint32_t w = sub; w < n_stat_rows; w += 32u) sv += stat_slab[(uint64_t)w * 8u + k];
+        part[threadIdx.x] = sv;
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            unsigned long long tot = 0;
+            for (uint32_t q = 0; q < 32u; q++) tot += part[q * 8u + threadIdx.x];
+            if (tot) atomicAdd(&stats[threadIdx.x], tot);
+        }
+        __syncthreads();
+    }
+    const uint32_t fx = threadIdx.x & 63u, ry = threadIdx.x >> 6;
+    const uint32_t f = blockIdx.x * 64u + fx;
+    unsigned long long sum = 0;
+    if (f < nf) {
+        const uint32_t step = F2Q_RED_SPLIT * 4u;
+#pragma unroll 8
+        for (uint32_t w = blockIdx.y * 4u + ry; w < n_rows; w += step) sum += slab[(uint64_t)w * nf + f];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (ry == 0 && f < nf) {
+        sum = part[fx] + part[64 + fx] + part[128 + fx] + part[192 + fx];
+        if (sum) atomicAdd(&counts[f], sum);
+    }
+}
+
+struct RawBlock {
+    uint64_t n;
+    uint64_t first_index;                  // global index of the block's read 0
+    const uint8_t *raw;                    // record bytes (host packer: seq then quality; device packer: the FASTQ text itself)
+    const unsigned long long *off;         // offset of the sequence line
+    const unsigned long long *qoff;        // offset of the quality line, or nullptr: it follows the sequence
+    const uint32_t *len, *qlen, *index;    // index: position inside the block (nullptr: == record id)
+};
+
+__global__ __launch_bounds__(256) void k_count_general(const RunDev *__restrict__ runp,
+                                                        const LibDev *__restrict__ libp, EcDev ec, RawBlock rb,
+                                                        Accum acc)
+{
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rb.n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        gbytes seq = gp(rb.raw) + gp(rb.off)[i];
+        const int r = (int)gp(rb.len)[i], qn = (int)gp(rb.qlen)[i];
+        gbytes qual = rb.qoff ? gp(rb.raw) + gp(rb.qoff)[i] : seq + r;
+        const unsigned long long gi = rb.first_index + (rb.index ? gp(rb.index)[i] : i);
+        general_read(run, lib, ec, acc, seq, r, qual, qn, gi, st);
+    }
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
+}
+

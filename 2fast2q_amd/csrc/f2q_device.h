@@ -1,5 +1,5 @@
 // f2q_device.h -- per-read logic of the counting path, written once as host/device inline
-// functions.  The HIP kernels (f2q_kernels.hip) call these per lane; tests/emu compiles the same
+// functions.  The HIP kernels (f2q_count_kernels.h) call these per lane; tests/emu compiles the same
 // functions with g++ to unit-test the lane logic on a machine without a GPU (test infrastructure
 // only -- the product never executes them on the host).
 //
@@ -1062,7 +1062,7 @@ F2Q_HD uint64_t plane_key(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], in
 
 // ---------------------------------------------------------------------------------------------
 // packing: which reads the tile planes can carry, and how one read is laid into them.  Shared by the
-// host packer (f2q_host.h) and the device packer (k_pack in f2q_kernels.hip).
+// host packer (f2q_host.h) and the device packer (k_pack in f2q_aux_kernels.h).
 // ---------------------------------------------------------------------------------------------
 #define F2Q_PACK_MAXLEN 512
 #define F2Q_ANCHOR_MAXLEN 160      // longest read the packed anchored kernel holds in registers (5 x 32 bases)
