@@ -393,3 +393,24 @@ def test_extract_count_fixed_window_gpu(P, start, length, rl):
         assert list(stats) == o.stats()
         assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts()))
         assert (t["fast_reads"] > 0) == (length <= 29)
+
+
+def test_fuzz_kernels_vs_oracle(P):
+    """250 seeded random cases (tests/fuzz_cases.py) through the C ABI: device packer + every kernel family"""
+    from fuzz_cases import make_case
+    fast = general = 0
+    for seed in range(250):
+        kw, feats, fq = make_case(seed)
+        o = O.Oracle(features=[(str(i), s) for i, s in enumerate(feats)] if feats is not None else None, **kw)
+        used_o = o.count_fastq(fq)
+        with P.Counter(features=feats, **kw) as c:
+            used, t = c.count_block(fq, want_timing=True)
+            counts, stats = c.read_counts()
+            assert used == used_o, (seed, kw)
+            assert list(stats) == o.stats(), (seed, kw)
+            if feats is not None:
+                assert list(counts) == o.counts(), (seed, kw)
+            else:
+                assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts())), (seed, kw)
+            fast += t["fast_reads"]; general += t["general_reads"]
+    assert fast > 1000 and general > 1000

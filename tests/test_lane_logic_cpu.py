@@ -212,3 +212,21 @@ def test_extract_count_fixed_window(start, length, rl):
     assert stats == o.stats()
     assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
     assert (fast > 0) == (length <= 29)          # windows longer than 29 bases use the byte-string table (general path)
+
+
+def test_fuzz_lane_logic_vs_oracle():
+    """400 seeded random cases (tests/fuzz_cases.py): every mode, awkward symbols / lengths / framing"""
+    from fuzz_cases import make_case
+    for seed in range(400):
+        kw, feats, fq = make_case(seed)
+        o = O.Oracle(features=[(str(i), s) for i, s in enumerate(feats)] if feats is not None else None, **kw)
+        used_o = o.count_fastq(fq)
+        e = Emu(features=feats, **kw)
+        used = e.count_block(fq)
+        counts, stats, _, _ = e.read()
+        assert used == used_o, (seed, kw)
+        assert stats == o.stats(), (seed, kw)
+        if feats is not None:
+            assert counts == o.counts(), (seed, kw)
+        else:
+            assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts())), (seed, kw)
