@@ -1,7 +1,7 @@
-"""one-off: many fuzz seeds through the C ABI (usage: python scripts/fuzz_gpu.py LO HI)"""
+"""one-off (GPU box): many fuzz seeds through the C ABI against the oracle -- usage: python tests/fuzz_gpu_many.py LO HI"""
 import importlib, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))   # R = repo root (this file sits in tests/)
 from fuzz_cases import make_case
 from oracle import oracle as O
 P = importlib.import_module("2fast2q_amd")
