@@ -9,11 +9,17 @@
 
 #include <algorithm>
 #include <string>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "f2q_device.h"
 #include "f2q_host.h"
 #include "f2q_synth.h"
+#include "f2q_reader.h"
 
 using namespace f2q;
 
@@ -69,9 +75,13 @@ struct f2q_ctx {
     bool force_general = false;           // F2Q_FORCE_GENERAL=1: every read through the byte-exact general kernel (cross-checks)
     bool force_v1 = false;                // F2Q_FORCE_V1=1: keep the one-read-per-lane kernel (A/B runs)
     std::string err;
+    // F2Q_TRACE=1: wall-clock split of the host entry points, printed by f2q_count_file (diagnostics only)
+    bool trace = false;
+    double tr_frame = 0, tr_count = 0, tr_free = 0;
 };
 
 static thread_local std::string g_create_err;
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int fail(f2q_ctx *c, int code, const std::string &msg)
 {
@@ -187,6 +197,7 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     for (int i = 0; i < p->n_downstream && i < F2Q_MAX_ITER; i++) c->down_s.push_back(p->downstream[i] ? p->downstream[i] : "");
     c->device = p->device;
     { const char *fv = getenv("F2Q_FORCE_V1"); c->force_v1 = fv && fv[0] == '1'; }
+    { const char *tr = getenv("F2Q_TRACE"); c->trace = tr && tr[0] == '1'; }
     { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_HOST_PACK"); c->host_pack = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_FORCE_GENERAL"); c->force_general = fv && fv[0] == '1'; }
@@ -722,6 +733,7 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
         // the device packer indexes the text with 32 bits: feed it at most 1 GiB at a time (record aligned by itself)
         const size_t take = std::min<size_t>(nbytes - pos, (size_t)1 << 30);
         f2q_block *b = nullptr; size_t used = 0;
+        const double t0 = now_ms();
         if (!c->host_pack) rc = block_from_text_device(c, fastq + pos, take, &used, &b);
         else {
             std::vector<Rec> recs;
@@ -730,8 +742,12 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
         }
         if (rc) return rc;
         f2q_timing one; memset(&one, 0, sizeof one);
+        const double t1 = now_ms();
         if (b && b->n_reads) rc = launch_block(c, b, t ? &one : nullptr);
+        if (c->trace) (void)hipStreamSynchronize(c->stream);
+        const double t2 = now_ms();
         if (b) f2q_block_free(c, b);
+        c->tr_frame += t1 - t0; c->tr_count += t2 - t1; c->tr_free += now_ms() - t2;
         if (rc) return rc;
         sum.kernel_ms += one.kernel_ms; sum.reads += one.reads; sum.fast_reads += one.fast_reads;
         sum.general_reads += one.general_reads; sum.launches += one.launches;
@@ -751,82 +767,118 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
     return F2Q_OK;
 }
 
-// reads_counter's file half (fast2q.py:560-578): gzip or plain by extension; streamed in blocks
+// ---- file streaming -------------------------------------------------------------------------------
+// Page-locked staging buffers are expensive to create (tens of ms per 256 MiB) and every file needs two, so
+// they are kept in a small process-wide pool between files (and between contexts: --cp runs several at once).
+struct PinBuf { uint8_t *p = nullptr; size_t cap = 0; };
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<PinBuf> idle;
+    size_t idle_bytes = 0;
+    static constexpr size_t KEEP_BYTES = (size_t)1200 << 20;
+    bool acquire(size_t cap, PinBuf &out)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].cap >= cap && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+            if (best < idle.size()) { out = idle[best]; idle_bytes -= out.cap; idle.erase(idle.begin() + (ptrdiff_t)best); return true; }
+        }
+        out.p = nullptr; out.cap = cap;
+        return hipHostMalloc((void **)&out.p, cap, hipHostMallocPortable) == hipSuccess;
+    }
+    void release(PinBuf &b)
+    {
+        if (!b.p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (idle_bytes + b.cap <= KEEP_BYTES && idle.size() < 8) { idle.push_back(b); idle_bytes += b.cap; b = PinBuf(); return; }
+        }
+        (void)hipHostFree(b.p); b = PinBuf();
+    }
+};
+static PinnedPool g_pinned;
+
+// reads_counter's file half (fast2q.py:560-578).  A reader thread (f2q_reader.h: parallel pread / parallel BGZF
+// inflate / gzread) fills one pinned buffer while the device frames, packs and counts the other; whole lines only
+// are handed over, the unconsumed tail (a partial record) is carried in front of the next piece.
 extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
 {
     if (!c || !path) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
-    size_t CH = (size_t)256 << 20;                 // bytes of text per block; F2Q_FILE_CHUNK overrides (tests)
+    size_t CH = (size_t)256 << 20;                 // bytes of text per piece; F2Q_FILE_CHUNK overrides (tests)
     { const char *e = getenv("F2Q_FILE_CHUNK"); if (e && atol(e) >= 4096) CH = (size_t)atol(e); }
-    // gzip by content (1f 8b), like gzip.open() by extension upstream (:567); plain files are read() straight
-    // into the pinned buffer, without zlib's pass-through copy
-    FILE *pf = fopen(path, "rb");
-    if (!pf) return fail(c, F2Q_EIO, std::string("cannot open ") + path);
-    unsigned char magic[2] = {0, 0};
-    const size_t got_magic = fread(magic, 1, 2, pf);
-    const bool is_gz = got_magic == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-    rewind(pf);
-    gzFile f = nullptr;
-    if (is_gz) {
-        fclose(pf); pf = nullptr;
-        f = gzopen(path, "rb");
-        if (!f) return fail(c, F2Q_EIO, std::string("cannot open ") + path);
-        gzbuffer(f, 1 << 20);
-    }
-    // page-locked staging buffer: the H2D copy of the text then runs at DMA speed
-    struct Pinned {
-        uint8_t *p = nullptr; size_t n = 0;
-        ~Pinned() { if (p) (void)hipHostFree(p); }
-        uint8_t *data() { return p; }
-        size_t size() const { return n; }
-        bool resize(size_t m) {
-            uint8_t *q = nullptr;
-            if (hipHostMalloc((void **)&q, m, hipHostMallocDefault) != hipSuccess) return false;
-            if (p) { memcpy(q, p, n < m ? n : m); (void)hipHostFree(p); }
-            p = q; n = m; return true;
+    TextSource src;
+    { std::string err; if (src.open(path, err) != 0) return fail(c, F2Q_EIO, err); }
+    const size_t HEAD = 64 << 10;                  // room in front of each piece for the carried tail
+    if (src.kind == TextSource::PLAIN && src.regular) CH = std::min<size_t>(CH, std::max<size_t>(src.file_size, 4096));
+    else if (src.regular) CH = std::min<size_t>(CH, std::max<size_t>(src.file_size * 16, (size_t)4 << 20));
+    const double tr_a = now_ms();
+    PinBuf buf[2];
+    auto drop = [&]() { g_pinned.release(buf[0]); g_pinned.release(buf[1]); };
+    if (!g_pinned.acquire(HEAD + CH, buf[0]) || !g_pinned.acquire(HEAD + CH, buf[1])) { drop(); return fail(c, F2Q_ENOMEM, "cannot allocate the pinned read buffers"); }
+    const double tr_b = now_ms();
+
+    struct Piece { int slot; size_t n; };
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Piece> ready; bool slot_free[2] = {true, true}; bool stop = false;
+    double read_ms = 0;
+    std::thread reader([&]() {
+        for (int slot = 0;; slot ^= 1) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot_free[slot] || stop; }); if (stop) return; slot_free[slot] = false; }
+            const double r0 = now_ms();
+            const size_t n = src.read(buf[slot].p + HEAD, CH);
+            read_ms += now_ms() - r0;
+            { std::lock_guard<std::mutex> g(mu); ready.push_back(Piece{slot, n}); }
+            cv.notify_all();
+            if (n == 0) return;
         }
-    } buf;
-    if (!buf.resize(CH)) { if (f) gzclose(f); if (pf) fclose(pf); return fail(c, F2Q_ENOMEM, "cannot allocate the pinned read buffer"); }
-    size_t have = 0;
+    });
+
     f2q_timing sum; memset(&sum, 0, sizeof sum);
-    int rc = F2Q_OK; bool truncated = false;
+    int rc = F2Q_OK;
+    std::vector<uint8_t> carry, big;
+    double wait_ms = 0;
     for (;;) {
-        long got;
-        if (f) {
-            got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
-            if (got < 0) { truncated = true; got = 0; }
-        } else got = (long)fread(buf.data() + have, 1, buf.size() - have, pf);
-        have += (size_t)got;
-        const bool eof = (got == 0);
-        if (have == 0) break;
-        size_t used = 0; f2q_timing one;
-        if (eof) {
-            rc = f2q_count_block(c, buf.data(), have, &used, &one);     // trailing partial record is dropped (:392)
-            used = have;
-        } else {
-            // only hand over whole lines: cut at the last newline so a line is never split between blocks
-            size_t cut = have;
-            while (cut > 0 && buf.data()[cut - 1] != 0x0a) cut--;
-            if (cut == 0) { if (have == buf.size() && !buf.resize(buf.size() * 2)) { rc = fail(c, F2Q_ENOMEM, "line longer than memory"); break; } continue; }
-            rc = f2q_count_block(c, buf.data(), cut, &used, &one);
+        Piece pc;
+        { const double w0 = now_ms(); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !ready.empty(); }); pc = ready.front(); ready.pop_front(); wait_ms += now_ms() - w0; }
+        const bool eof = (pc.n == 0);
+        uint8_t *base; size_t have;
+        if (carry.size() <= HEAD) {
+            base = buf[pc.slot].p + HEAD - carry.size();
+            if (!carry.empty()) memcpy(base, carry.data(), carry.size());
+            have = carry.size() + pc.n;
+        } else {                                   // a tail longer than the head room (very long lines): pageable detour
+            big.resize(carry.size() + pc.n);
+            memcpy(big.data(), carry.data(), carry.size());
+            if (pc.n) memcpy(big.data() + carry.size(), buf[pc.slot].p + HEAD, pc.n);
+            base = big.data(); have = big.size();
         }
-        if (rc) break;
-        sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
-        sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
-        memmove(buf.data(), buf.data() + used, have - used);
-        have -= used;
-        if (eof) break;
-        if (have == buf.size() && !buf.resize(buf.size() * 2)) { rc = fail(c, F2Q_ENOMEM, "record longer than memory"); break; }
+        size_t used = 0;
+        if (have) {
+            f2q_timing one; memset(&one, 0, sizeof one);
+            if (eof) { rc = f2q_count_block(c, base, have, &used, &one); used = have; }   // trailing partial record is dropped (:392)
+            else {
+                size_t cut = have;                 // only whole lines: a line is never split between blocks
+                while (cut > 0 && base[cut - 1] != 0x0a) cut--;
+                if (cut) rc = f2q_count_block(c, base, cut, &used, &one);
+            }
+            sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
+            sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
+        }
+        if (!rc) { std::vector<uint8_t> rest(base + used, base + have); carry.swap(rest); }
+        { std::lock_guard<std::mutex> g(mu); slot_free[pc.slot] = true; if (rc || eof) stop = true; }
+        cv.notify_all();
+        if (rc || eof) break;
     }
-    if (f) {
-        int zerr = 0; (void)gzerror(f, &zerr);
-        if (zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) truncated = true;
-        gzclose(f);
-    }
-    if (pf) fclose(pf);
+    reader.join();
+    drop();
     if (t) *t = sum;
+    if (c->trace) fprintf(stderr, "[f2q trace] %s (%s, %d io threads): pinned %.1f ms, reader busy %.1f ms, waited for reader %.1f ms, frame+pack %.1f ms, count %.1f ms, free %.1f ms\n",
+                          path, src.kind_name(), src.n_threads, tr_b - tr_a, read_ms, wait_ms, c->tr_frame, c->tr_count, c->tr_free);
     if (rc) return rc;
-    if (truncated) return fail(c, F2Q_ETRUNCATED, std::string(path) + " is an incomplete or corrupted gzip file");
+    if (src.truncated()) return fail(c, F2Q_ETRUNCATED, std::string(path) + " is an incomplete or corrupted gzip file");
     return F2Q_OK;
 }
 

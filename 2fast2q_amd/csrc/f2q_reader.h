@@ -1,0 +1,308 @@
+// File side of reads_counter (fast2q.py:560-578: `gzip.open(raw)` / `open(raw)` by extension, then line iteration).
+// Host only (no HIP): a byte source that hands out the decoded FASTQ text in caller-sized pieces.
+//
+//   PLAIN  regular files are read with several pread() workers straight into the caller's (pinned) buffer
+//   BGZF   blocked gzip (bgzip, BCL Convert, samtools): every member carries its compressed size in a 'BC'
+//          extra field, so the members of one batch are inflated by a pool of workers, each straight into its
+//          final place in the caller's buffer; CRC32 and ISIZE of every member are checked like gzip does
+//   GZIP   anything else that starts with 1f 8b: zlib's gzread (one sequential inflate; multi-member aware)
+//
+// A BGZF file that turns into ordinary gzip half way (concatenated files) is continued with gzread from the
+// uncompressed offset reached.  A damaged or cut-off stream delivers the text before the damage and then
+// reports `truncated()` — the reference returns None for such a file (:580-582), the harness does the same.
+#pragma once
+#include <fcntl.h>
+#include <stdint.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct TextSource {
+    enum Kind { NONE, PLAIN, GZIP, BGZF };
+    Kind kind = NONE;
+    int fd = -1;
+    gzFile gz = nullptr;
+    std::string path;
+    bool regular = false, bad = false, done = false;
+    uint64_t file_size = 0, file_pos = 0;       // PLAIN / BGZF: compressed bytes taken from the file
+    uint64_t out_total = 0;                     // decoded bytes handed out so far
+    int n_threads = 1;
+    // BGZF state
+    std::vector<uint8_t> cbuf;                  // compressed bytes not yet inflated
+    size_t cpos = 0;                            // first unconsumed byte of cbuf
+    bool c_eof = false;
+    std::vector<uint8_t> spill;                 // a member larger than the caller's remaining room
+    size_t spill_pos = 0;
+
+    ~TextSource() { close(); }
+
+    static int default_threads()
+    {
+        const char *e = getenv("F2Q_IO_THREADS");
+        if (e && atoi(e) >= 1) return std::min(atoi(e), 64);
+        unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+    }
+
+    bool truncated() const { return bad; }
+    const char *kind_name() const { return kind == PLAIN ? "plain" : kind == BGZF ? "bgzf" : kind == GZIP ? "gzip" : "none"; }
+
+    // 0 on success
+    int open(const char *p, std::string &err)
+    {
+        close();
+        path = p; n_threads = default_threads();
+        fd = ::open(p, O_RDONLY);
+        if (fd < 0) { err = std::string("cannot open ") + p; return -1; }
+        struct stat st;
+        regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+        file_size = regular ? (uint64_t)st.st_size : 0;
+        uint8_t head[4096];
+        size_t got = 0;
+        if (regular) { ssize_t r = pread(fd, head, sizeof head, 0); got = r > 0 ? (size_t)r : 0; }
+        if (got >= 2 && head[0] == 0x1f && head[1] == 0x8b) {
+            uint32_t bsize;
+            if (bgzf_header(head, got, bsize)) { kind = BGZF; return 0; }
+            return open_gzip(0, err);
+        }
+        if (!regular) {                                   // pipes cannot be sniffed: go by the name, like upstream (:567)
+            const size_t L = path.size();
+            if (L >= 3 && path.compare(L - 3, 3, ".gz") == 0) return open_gzip(0, err);
+        }
+        kind = PLAIN;
+        return 0;
+    }
+
+    void close()
+    {
+        if (gz) { gzclose(gz); gz = nullptr; }
+        if (fd >= 0) { ::close(fd); fd = -1; }
+        kind = NONE; bad = done = c_eof = false; file_pos = out_total = 0; cbuf.clear(); cpos = 0; spill.clear(); spill_pos = 0;
+    }
+
+    // up to `cap` bytes of text into dst; 0 = end of the data (then see truncated())
+    size_t read(uint8_t *dst, size_t cap)
+    {
+        if (done || cap == 0) return 0;
+        size_t n = 0;
+        if (kind == PLAIN) n = read_plain(dst, cap);
+        else if (kind == GZIP) n = read_gzip(dst, cap);
+        else if (kind == BGZF) n = read_bgzf(dst, cap);
+        if (n == 0) done = true;
+        out_total += n;
+        return n;
+    }
+
+private:
+    int open_gzip(uint64_t skip, std::string &err)
+    {
+        if (fd >= 0) { ::close(fd); fd = -1; }
+        gz = gzopen(path.c_str(), "rb");
+        if (!gz) { err = std::string("cannot open ") + path; return -1; }
+        gzbuffer(gz, 1 << 20);
+        kind = GZIP;
+        if (skip && gzseek(gz, (z_off_t)skip, SEEK_SET) < 0) bad = true;
+        return 0;
+    }
+
+    // ---- plain --------------------------------------------------------------------------------------
+    size_t read_plain(uint8_t *dst, size_t cap)
+    {
+        if (!regular) {                                   // pipes, /dev/stdin: sequential
+            size_t n = 0;
+            while (n < cap) {
+                ssize_t r = ::read(fd, dst + n, cap - n);
+                if (r <= 0) break;
+                n += (size_t)r;
+            }
+            return n;
+        }
+        const uint64_t left = file_size > file_pos ? file_size - file_pos : 0;
+        const size_t want = (size_t)std::min<uint64_t>(left, cap);
+        if (want == 0) return 0;
+        const size_t slice_min = (size_t)4 << 20;
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, want / slice_min));
+        std::atomic<bool> short_read{false};
+        auto work = [&](int t) {
+            const size_t a = want * (size_t)t / (size_t)T, b = want * (size_t)(t + 1) / (size_t)T;
+            size_t o = a;
+            while (o < b) {
+                ssize_t r = pread(fd, dst + o, b - o, (off_t)(file_pos + o));
+                if (r <= 0) { short_read = true; return; }
+                o += (size_t)r;
+            }
+        };
+        if (T == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        if (short_read) { bad = true; return 0; }         // the file shrank under us
+        file_pos += want;
+        return want;
+    }
+
+    // ---- ordinary gzip -----------------------------------------------------------------------------
+    size_t read_gzip(uint8_t *dst, size_t cap)
+    {
+        if (bad) return 0;
+        size_t n = 0;
+        while (n < cap) {
+            int r = gzread(gz, dst + n, (unsigned)std::min<size_t>(cap - n, 1u << 30));
+            if (r < 0) { bad = true; break; }
+            if (r == 0) {
+                int zerr = 0; (void)gzerror(gz, &zerr);
+                if (zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) bad = true;
+                break;
+            }
+            n += (size_t)r;
+        }
+        return n;
+    }
+
+    // ---- BGZF ---------------------------------------------------------------------------------------
+    // gzip member header with a 'BC' extra subfield: *bsize = whole member size in bytes
+    static bool bgzf_header(const uint8_t *h, size_t avail, uint32_t &bsize)
+    {
+        if (avail < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return false;     // BGZF: FLG = FEXTRA only
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        if (avail < 12 + (size_t)xlen) return false;
+        for (uint32_t o = 0; o + 4 <= xlen;) {
+            const uint8_t *sf = h + 12 + o;
+            const uint32_t slen = sf[2] | (sf[3] << 8);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && o + 6 <= xlen) { bsize = (sf[4] | (sf[5] << 8)) + 1u; return true; }
+            o += 4 + slen;
+        }
+        return false;
+    }
+
+    struct Member { size_t c_off; uint32_t c_len, hdr, isize; size_t o_off; };
+
+    bool fill_cbuf(size_t want_more)
+    {
+        if (c_eof) return false;
+        const size_t old = cbuf.size();
+        cbuf.resize(old + want_more);
+        size_t n = 0;
+        while (n < want_more) {
+            ssize_t r = pread(fd, cbuf.data() + old + n, want_more - n, (off_t)file_pos);
+            if (r <= 0) { c_eof = true; break; }
+            n += (size_t)r; file_pos += (uint64_t)r;
+        }
+        cbuf.resize(old + n);
+        return n > 0;
+    }
+
+    static bool inflate_member(const uint8_t *src, const Member &m, uint8_t *out)
+    {
+        if (m.c_len < m.hdr + 8) return false;
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef *>(src + m.c_off + m.hdr); zs.avail_in = m.c_len - m.hdr - 8;
+        zs.next_out = out; zs.avail_out = m.isize;
+        Bytef dummy[8];
+        if (m.isize == 0) { zs.next_out = dummy; zs.avail_out = sizeof dummy; }
+        const int r = inflate(&zs, Z_FINISH);
+        const bool ok = (r == Z_STREAM_END) && zs.total_out == m.isize && zs.avail_in == 0;
+        inflateEnd(&zs);
+        if (!ok) return false;
+        const uint8_t *tail = src + m.c_off + m.c_len - 8;
+        const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, m.isize) == crc;
+    }
+
+    size_t read_bgzf(uint8_t *dst, size_t cap)
+    {
+        size_t n = 0;
+        if (spill_pos < spill.size()) {                   // rest of a member that did not fit last time
+            const size_t k = std::min(cap, spill.size() - spill_pos);
+            memcpy(dst, spill.data() + spill_pos, k);
+            spill_pos += k; n = k;
+            if (spill_pos == spill.size()) { spill.clear(); spill_pos = 0; }
+            return n;
+        }
+        if (bad) return 0;
+        if (cpos > 0) { cbuf.erase(cbuf.begin(), cbuf.begin() + (ptrdiff_t)cpos); cpos = 0; }   // offsets below index cbuf: compact only here
+        std::vector<Member> ms;
+        size_t scan = cpos, o_off = 0;
+        bool foreign = false;
+        for (;;) {
+            if (cbuf.size() - scan < 18) {
+                if (!fill_cbuf((size_t)32 << 20)) {
+                    if (cbuf.size() - scan > 0) bad = true;       // a few stray bytes: cut-off header
+                    break;
+                }
+                continue;
+            }
+            uint32_t bsize;
+            const uint8_t *h = cbuf.data() + scan;
+            const uint32_t xlen = h[10] | (h[11] << 8);
+            if (cbuf.size() - scan < 12 + (size_t)xlen && !c_eof) { fill_cbuf((size_t)32 << 20); continue; }
+            if (!bgzf_header(h, cbuf.size() - scan, bsize)) {
+                if (h[0] == 0x1f && h[1] == 0x8b) foreign = true; else bad = true;     // ordinary gzip member / garbage
+                break;
+            }
+            if (cbuf.size() - scan < bsize) {
+                if (!fill_cbuf((size_t)32 << 20)) { bad = true; break; }               // member cut off
+                continue;
+            }
+            if (bsize < 12 + xlen + 8) { bad = true; break; }
+            const uint8_t *tail = cbuf.data() + scan + bsize - 4;
+            const uint32_t isize = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+            if (o_off + isize > cap) {
+                if (!ms.empty()) break;                           // next call
+                // one member larger than the room offered: inflate aside and hand out in pieces
+                Member m{scan, bsize, 12 + xlen, isize, 0};
+                spill.assign(isize, 0); spill_pos = 0;
+                if (!inflate_member(cbuf.data(), m, spill.data())) { spill.clear(); bad = true; return 0; }
+                cpos = scan + bsize;
+                return read_bgzf(dst, cap);
+            }
+            ms.push_back(Member{scan, bsize, 12 + xlen, isize, o_off});
+            o_off += isize; scan += bsize;
+            if (ms.size() >= 65536) break;
+        }
+        if (!ms.empty()) {
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, ms.size() / 4));
+            std::atomic<size_t> next{0}, first_bad{ms.size()};
+            auto work = [&]() {
+                for (;;) {
+                    const size_t i = next.fetch_add(16);
+                    if (i >= ms.size()) return;
+                    for (size_t j = i; j < std::min(i + 16, ms.size()); j++)
+                        if (!inflate_member(cbuf.data(), ms[j], dst + ms[j].o_off)) {
+                            size_t cur = first_bad.load();
+                            while (j < cur && !first_bad.compare_exchange_weak(cur, j)) {}
+                        }
+                }
+            };
+            if (T == 1) work();
+            else {
+                std::vector<std::thread> th;
+                for (int t = 1; t < T; t++) th.emplace_back(work);
+                work();
+                for (auto &x : th) x.join();
+            }
+            const size_t fb = first_bad.load();
+            if (fb < ms.size()) { bad = true; foreign = false; n = ms[fb].o_off; cpos = ms[fb].c_off; }
+            else { n = o_off; cpos = scan; }
+        }
+        if (n == 0 && foreign && !bad) {                      // the rest is ordinary gzip: let zlib walk it
+            std::string err;
+            if (open_gzip(out_total, err) != 0) { bad = true; return 0; }
+            return read_gzip(dst, cap);
+        }
+        // empty members (the BGZF end marker) produce nothing: keep going until text or the end
+        if (n == 0 && !bad && !ms.empty()) return read_bgzf(dst, cap);
+        return n;
+    }
+};

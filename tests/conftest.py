@@ -7,6 +7,8 @@ C-ABI and are the parity tests proper.
 import importlib
 import json
 import os
+import struct
+import zlib
 import sys
 
 import pytest
@@ -74,3 +76,20 @@ def sprinkle_symbols(fastq, seed, rate=0.08, symbols=b"NnRacgtY."):
                 b[j] = ord(chr(b[j]).lower()) if c in b"acgt" and rng.random() < 0.5 else c
         lines[i] = bytes(b)
     return b"\n".join(lines)
+
+
+def bgzf_bytes(data, block=0xFF00, level=6, eof_marker=True, extra_subfield=False):
+    """BGZF as bgzip writes it: gzip members with a 'BC' extra subfield holding the member size - 1."""
+    out = bytearray()
+    pieces = [data[i:i + block] for i in range(0, len(data), block)]
+    if eof_marker:
+        pieces.append(b"")
+    for p in pieces:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(p) + co.flush()
+        extra = (b"XY" + struct.pack("<H", 3) + b"abc" if extra_subfield else b"") + b"BC" + struct.pack("<H", 2)
+        xlen = len(extra) + 2
+        bsize = 12 + xlen + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", xlen) + extra + struct.pack("<H", bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(p) & 0xFFFFFFFF, len(p))
+    return bytes(out)

@@ -14,6 +14,7 @@
 #include "../../2fast2q_amd/csrc/f2q_device.h"
 #include "../../2fast2q_amd/csrc/f2q_host.h"
 #include "../../2fast2q_amd/csrc/f2q_synth.h"
+#include "../../2fast2q_amd/csrc/f2q_reader.h"
 
 using namespace f2q;
 
@@ -341,6 +342,26 @@ size_t emu_synth_fastq(void *h, const f2q_synth *s, uint64_t lo, uint64_t hi, ui
         o += R; buf[o++] = '\n';
     }
     return o;
+}
+
+// the file reader of f2q_count_file (f2q_reader.h), piece size `cap`: returns the bytes decoded, -1 if out is too small
+long long emu_read_file(const char *path, size_t cap, int threads, uint8_t *out, size_t out_cap, int *truncated, int *kind)
+{
+    TextSource src; std::string err;
+    if (src.open(path, err) != 0) return -2;
+    if (threads > 0) src.n_threads = threads;
+    if (kind) *kind = (int)src.kind;
+    std::vector<uint8_t> piece(cap);
+    size_t total = 0;
+    for (;;) {
+        const size_t n = src.read(piece.data(), cap);
+        if (n == 0) break;
+        if (total + n > out_cap) return -1;
+        memcpy(out + total, piece.data(), n); total += n;
+    }
+    if (truncated) *truncated = src.truncated() ? 1 : 0;
+    if (kind) *kind = (int)src.kind;
+    return (long long)total;
 }
 
 } // extern "C"

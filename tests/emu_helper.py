@@ -16,10 +16,10 @@ binding = importlib.import_module("2fast2q_amd.binding")
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("f2q_device.h", "f2q_host.h", "f2q_synth.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("f2q_device.h", "f2q_host.h", "f2q_synth.h", "f2q_reader.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-                               "-o", LIB, SRC])
+                               "-o", LIB, SRC, "-lz", "-lpthread"])
     return LIB
 
 
@@ -53,8 +53,21 @@ def lib():
                                  C.POINTER(C.c_uint64)]
         L.emu_synth_fastq.restype = C.c_size_t
         L.emu_synth_fastq.argtypes = [vp, C.POINTER(binding.Synth), C.c_uint64, C.c_uint64, C.c_char_p]
+        L.emu_read_file.restype = C.c_longlong
+        L.emu_read_file.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int)]
         _L = L
     return _L
+
+
+def read_file(path, piece=1 << 16, threads=0, out_cap=1 << 26):
+    """Decode `path` with the product's file reader (f2q_reader.h) -> (bytes, truncated, kind)."""
+    out = C.create_string_buffer(out_cap)
+    tr, kind = C.c_int(0), C.c_int(0)
+    n = lib().emu_read_file(os.fsencode(path), piece, threads, out, out_cap, C.byref(tr), C.byref(kind))
+    if n < 0:
+        raise RuntimeError(f"emu_read_file rc {n}")
+    return out.raw[:n], bool(tr.value), {1: "plain", 2: "gzip", 3: "bgzf"}.get(kind.value, "none")
 
 
 class Emu:

@@ -7,7 +7,7 @@ import os
 import pytest
 
 import synth
-from conftest import ROOT, pkg
+from conftest import ROOT, bgzf_bytes, pkg
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -177,7 +177,7 @@ def test_console_script_like_the_reference_test(tmp_path):
     assert len(files) == 6 and (subdirs[0] / "compiled.csv").exists()
 
 
-@pytest.mark.parametrize("gz", [False, True])
+@pytest.mark.parametrize("gz", ["plain", "gzip", "bgzf"])
 @pytest.mark.parametrize("chunk", ["4096", "65536", "1000003"])
 def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk):
     """f2q_count_file streams a file in blocks: records and lines that straddle a block boundary, a block that
@@ -188,8 +188,8 @@ def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk
     fq = fq.replace(b"\n", b"\r\n", 3000)                      # some CRLF line ends
     fq += b"@long\n" + b"ACGT" * 3000 + b"\n+\n" + b"I" * 12000 + b"\n"      # a 12 kb read: longer than the smallest chunk
     fq += synth.make_fastq(synth.Spec(seed=81, n_reads=500, read_len=40), guides)[:-1]   # no final newline
-    path = tmp_path / ("f.fastq.gz" if gz else "f.fastq")
-    (gzip.open(path, "wb") if gz else open(path, "wb")).write(fq)
+    path = tmp_path / ("f.fastq" if gz == "plain" else "f.fastq.gz")
+    path.write_bytes({"plain": fq, "gzip": gzip.compress(fq, 1), "bgzf": bgzf_bytes(fq, block=20000)}[gz])
     for kw in (dict(miss=1), dict(mode="EC", upstream="ACGT", length=9)):
         orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)] if "mode" not in kw else None, **kw)
         orc.count_fastq(fq)

@@ -1,0 +1,124 @@
+"""The file reader behind f2q_count_file (2fast2q_amd/csrc/f2q_reader.h) against Python's own gzip/open — the
+decoders the reference uses (fast2q.py:565-569).  Host only."""
+import gzip, os, random, zlib
+import pytest
+from conftest import bgzf_bytes
+from emu_helper import read_file
+
+
+def text(n, seed=1):
+    rng = random.Random(seed)
+    rec = []
+    for i in range(n):
+        L = rng.randint(20, 160)
+        rec.append("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGTN") for _ in range(L)), "I" * L))
+    return "".join(rec).encode()
+
+
+@pytest.fixture(scope="module")
+def payload():
+    return text(12000)
+
+
+@pytest.mark.parametrize("piece", [4096, 1 << 16, 100_003, 1 << 22])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_plain(tmp_path, payload, piece, threads):
+    p = tmp_path / "a.fastq"; p.write_bytes(payload)
+    got, tr, kind = read_file(p, piece, threads)
+    assert (got, tr, kind) == (payload, False, "plain")
+
+
+def test_plain_parallel_slices(tmp_path):
+    data = os.urandom(40 << 20).replace(b"\x1f\x8b", b"ab")
+    p = tmp_path / "big.fastq"; p.write_bytes(data)
+    got, tr, kind = read_file(p, 24 << 20, 5, out_cap=48 << 20)
+    assert kind == "plain" and not tr and got == data
+
+
+def test_empty_files(tmp_path):
+    p = tmp_path / "e.fastq"; p.write_bytes(b"")
+    assert read_file(p) == (b"", False, "plain")
+    z = tmp_path / "e.fastq.gz"
+    with gzip.open(z, "wb") as f: pass
+    got, tr, kind = read_file(z)
+    assert (got, tr) == (b"", False)
+    b = tmp_path / "e2.fastq.gz"; b.write_bytes(bgzf_bytes(b""))
+    assert read_file(b) == (b"", False, "bgzf")
+
+
+@pytest.mark.parametrize("piece", [4096, 1 << 16, 1 << 22])
+def test_gzip_single_and_multi_member(tmp_path, payload, piece):
+    z = tmp_path / "a.fastq.gz"
+    with gzip.open(z, "wb", compresslevel=1) as f: f.write(payload)
+    assert read_file(z, piece) == (payload, False, "gzip")
+    half = len(payload) // 2
+    z2 = tmp_path / "b.fastq.gz"; z2.write_bytes(gzip.compress(payload[:half]) + gzip.compress(payload[half:]))
+    assert gzip.open(z2).read() == payload
+    assert read_file(z2, piece) == (payload, False, "gzip")
+
+
+@pytest.mark.parametrize("piece", [4096, 1 << 16, 300_000, 1 << 22])
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_bgzf(tmp_path, payload, piece, threads):
+    b = tmp_path / "a.fastq.gz"; b.write_bytes(bgzf_bytes(payload))
+    assert gzip.open(b).read() == payload                      # what the reference would see
+    assert read_file(b, piece, threads) == (payload, False, "bgzf")
+
+
+def test_bgzf_variants(tmp_path, payload):
+    for k, kw in enumerate([dict(block=1000), dict(block=65280, level=1), dict(eof_marker=False), dict(extra_subfield=True, block=5000),
+                            dict(block=17, level=0)]):
+        data = payload if kw.get("block", 0) != 17 else payload[:20000]
+        b = tmp_path / f"v{k}.gz"; b.write_bytes(bgzf_bytes(data, **kw))
+        assert gzip.open(b).read() == data
+        assert read_file(b, 1 << 16, 4) == (data, False, "bgzf"), kw
+
+
+def test_bgzf_empty_members_inside(tmp_path, payload):
+    raw = bgzf_bytes(payload[:5000], eof_marker=True) + bgzf_bytes(payload[5000:9000], eof_marker=True) + bgzf_bytes(payload[9000:])
+    b = tmp_path / "m.gz"; b.write_bytes(raw)
+    assert gzip.open(b).read() == payload
+    assert read_file(b, 8192, 4) == (payload, False, "bgzf")
+
+
+@pytest.mark.parametrize("cut", [10, 30, 1000, 70_000, -9, -1])
+def test_bgzf_cut_off(tmp_path, payload, cut):
+    raw = bgzf_bytes(payload, eof_marker=False)
+    raw = raw[:cut]
+    b = tmp_path / "t.gz"; b.write_bytes(raw)
+    with pytest.raises((EOFError, gzip.BadGzipFile, zlib.error)):
+        gzip.open(b).read()
+    got, tr, kind = read_file(b, 1 << 16, 4)
+    assert tr and payload.startswith(got)
+    # every member that is whole is delivered
+    whole = 0
+    for i in range(0, len(payload), 0xFF00):
+        if len(bgzf_bytes(payload[:i + 0xFF00], eof_marker=False)) <= len(raw): whole = min(i + 0xFF00, len(payload))
+    assert len(got) == whole
+
+
+def test_bgzf_corrupt_member(tmp_path, payload):
+    raw = bytearray(bgzf_bytes(payload, block=4000))
+    raw[len(raw) // 2] ^= 0x55
+    b = tmp_path / "c.gz"; b.write_bytes(bytes(raw))
+    got, tr, kind = read_file(b, 1 << 16, 4)
+    assert tr and kind == "bgzf" and payload.startswith(got) and len(got) < len(payload)
+
+
+def test_bgzf_then_ordinary_gzip(tmp_path, payload):
+    a, c = payload[:100_000], payload[100_000:]
+    b = tmp_path / "mix.gz"; b.write_bytes(bgzf_bytes(a, eof_marker=False) + gzip.compress(c))
+    assert gzip.open(b).read() == payload
+    got, tr, kind = read_file(b, 1 << 16, 4)
+    assert (got, tr, kind) == (payload, False, "gzip")
+
+
+def test_gzip_cut_off(tmp_path, payload):
+    z = tmp_path / "t.fastq.gz"; z.write_bytes(gzip.compress(payload)[:-2000])
+    got, tr, kind = read_file(z)
+    assert tr and kind == "gzip" and payload.startswith(got)
+
+
+def test_gz_content_sniffed_not_named(tmp_path, payload):
+    z = tmp_path / "noext"; z.write_bytes(gzip.compress(payload))
+    assert read_file(z)[0] == payload
