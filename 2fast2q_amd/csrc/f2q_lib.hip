@@ -12,6 +12,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
+#include <unordered_map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -74,10 +76,15 @@ struct f2q_ctx {
     bool host_pack = false;               // F2Q_HOST_PACK=1: frame/classify/pack on the host (the round-1 first path; A/B runs)
     bool force_general = false;           // F2Q_FORCE_GENERAL=1: every read through the byte-exact general kernel (cross-checks)
     bool force_v1 = false;                // F2Q_FORCE_V1=1: keep the one-read-per-lane kernel (A/B runs)
+    // device memory freed by blocks / scratch is kept (idle, after a stream sync) for the next piece of the same
+    // size class: a streamed file costs ~20 allocations per piece otherwise
+    std::multimap<size_t, void *> dev_idle;
+    std::unordered_map<void *, size_t> dev_size;
+    size_t dev_idle_bytes = 0, dev_idle_cap = (size_t)8 << 30;
     std::string err;
     // F2Q_TRACE=1: wall-clock split of the host entry points, printed by f2q_count_file (diagnostics only)
     bool trace = false;
-    double tr_frame = 0, tr_count = 0, tr_free = 0;
+    double tr_frame = 0, tr_count = 0, tr_free = 0, tr_copy = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -96,12 +103,32 @@ static int fail(f2q_ctx *c, int code, const std::string &msg)
             return fail(ctx, F2Q_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+static int dev_get(f2q_ctx *c, size_t bytes, void **out)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = c->dev_idle.lower_bound(bytes);
+    if (it != c->dev_idle.end() && it->first <= bytes + bytes / 4 + (64 << 10)) {
+        *out = it->second; c->dev_idle_bytes -= it->first; c->dev_idle.erase(it);
+        return F2Q_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess && !c->dev_idle.empty()) {           // give the idle memory back and retry once
+        for (auto &kv : c->dev_idle) { c->dev_size.erase(kv.second); (void)hipFree(kv.second); }
+        c->dev_idle.clear(); c->dev_idle_bytes = 0;
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) return fail(c, F2Q_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    c->dev_size[p] = bytes;
+    *out = p;
+    return F2Q_OK;
+}
 template <class T>
 static int dev_upload(f2q_ctx *c, const T *src, size_t n, T **dst, std::vector<void *> &owner)
 {
     void *p = nullptr;
-    size_t bytes = (n ? n : 1) * sizeof(T);
-    HIPC(c, hipMalloc(&p, bytes));
+    int rc = dev_get(c, (n ? n : 1) * sizeof(T), &p);
+    if (rc) return rc;
     owner.push_back(p);
     if (n) HIPC(c, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     *dst = (T *)p;
@@ -112,15 +139,28 @@ static int dev_alloc(f2q_ctx *c, size_t n, T **dst, std::vector<void *> &owner, 
 {
     void *p = nullptr;
     size_t bytes = (n ? n : 1) * sizeof(T);
-    HIPC(c, hipMalloc(&p, bytes));
+    int rc = dev_get(c, bytes, &p);
+    if (rc) return rc;
     owner.push_back(p);
     if (fill >= 0) HIPC(c, hipMemsetAsync(p, fill, bytes, c->stream));
     *dst = (T *)p;
     return F2Q_OK;
 }
-static void free_all(std::vector<void *> &v)
+// memory goes back to the idle list only once nothing queued on the stream can still touch it
+static void free_all(f2q_ctx *c, std::vector<void *> &v)
 {
-    for (void *p : v) (void)hipFree(p);
+    if (v.empty()) return;
+    if (!c) { for (void *p : v) (void)hipFree(p); v.clear(); return; }      // block outliving its context
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : v) {
+        auto it = c->dev_size.find(p);
+        if (it != c->dev_size.end() && c->dev_idle_bytes + it->second <= c->dev_idle_cap) {
+            c->dev_idle.emplace(it->second, p); c->dev_idle_bytes += it->second;
+        } else {
+            if (it != c->dev_size.end()) c->dev_size.erase(it);
+            (void)hipFree(p);
+        }
+    }
     v.clear();
 }
 
@@ -145,7 +185,7 @@ static int setup_run(f2q_ctx *c)
 
 static int upload_lib(f2q_ctx *c)
 {
-    free_all(c->lib_allocs);
+    free_all(c, c->lib_allocs);
     LibDev &L = c->lib_h;
     memset(&L, 0, sizeof L);
     L.n_features = c->ix.n_features;
@@ -235,7 +275,9 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    free_all(c->lib_allocs); free_all(c->ec_allocs);
+    free_all(c, c->lib_allocs); free_all(c, c->ec_allocs);
+    for (auto &kv : c->dev_idle) (void)hipFree(kv.second);
+    c->dev_idle.clear(); c->dev_size.clear();
     if (c->acc_d) (void)hipFree(c->acc_d);
     if (c->synth_keys_d) (void)hipFree(c->synth_keys_d);
     if (c->slab_d) (void)hipFree(c->slab_d);
@@ -280,7 +322,7 @@ extern "C" int f2q_reset_counts(f2q_ctx *c)
     if (!c) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemsetAsync(c->acc_d, 0, c->acc_n * sizeof(unsigned long long), c->stream));
-    if (c->prm.mode == 1) { free_all(c->ec_allocs); memset(&c->ec, 0, sizeof c->ec); c->ec_slots = 0; }
+    if (c->prm.mode == 1) { free_all(c, c->ec_allocs); memset(&c->ec, 0, sizeof c->ec); c->ec_slots = 0; }
     c->reads_seen = 0;
     HIPC(c, hipStreamSynchronize(c->stream));
     return F2Q_OK;
@@ -350,7 +392,7 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
     uint64_t ne = std::max<uint64_t>(need_e * 2, 1u << 16), nw = std::max<uint64_t>(need_w * 2, 1u << 18);
     EcDev fresh; std::vector<void *> owner;
     int rc = ec_alloc(c, fresh, owner, ne, nw);
-    if (rc) { free_all(owner); return rc; }
+    if (rc) { free_all(c, owner); return rc; }
     if (c->ec.slots && ctr[0]) {
         hipLaunchKernelGGL(k_ec_rehash, dim3((unsigned)((ctr[0] + 255) / 256)), dim3(256), 0, c->stream, c->ec, ctr[0], fresh);
         HIPC(c, hipGetLastError());
@@ -360,7 +402,7 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
         HIPC(c, hipGetLastError());
     }
     HIPC(c, hipStreamSynchronize(c->stream));
-    free_all(c->ec_allocs);
+    free_all(c, c->ec_allocs);
     c->ec_allocs = owner; c->ec = fresh;
     return F2Q_OK;
 }
@@ -556,7 +598,7 @@ extern "C" void f2q_block_free(f2q_ctx *c, f2q_block *b)
 {
     if (!b) return;
     if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
-    free_all(b->allocs);
+    free_all(c, b->allocs);
     delete b;
 }
 
@@ -603,7 +645,7 @@ static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_bloc
         hipError_t e = hipStreamSynchronize(c->stream);      // host staging vectors die with this frame
         if (e != hipSuccess) { rc = fail(c, F2Q_EHIP, hipGetErrorString(e)); break; }
     } while (0);
-    if (rc) { free_all(b->allocs); delete b; return rc; }
+    if (rc) { free_all(c, b->allocs); delete b; return rc; }
     *out = b;
     return F2Q_OK;
 }
@@ -618,7 +660,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     if (nbytes == 0) { *out = b; return F2Q_OK; }    // an empty buffer is an empty block
     std::vector<void *> tmp;                         // scratch freed before returning
     int rc = F2Q_OK;
-    auto bail = [&](int code) { free_all(tmp); free_all(b->allocs); delete b; return code; };
+    auto bail = [&](int code) { free_all(c, tmp); free_all(c, b->allocs); delete b; return code; };
     const uint32_t n_chunks = (uint32_t)((nbytes + F2Q_NL_CHUNK - 1) / F2Q_NL_CHUNK);
     const size_t padded = (size_t)n_chunks * F2Q_NL_CHUNK + 16;
     uint8_t *d_text; uint32_t *d_cc, *d_cp;
@@ -627,7 +669,9 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     if ((rc = dev_alloc(c, (size_t)n_chunks + 1, &d_cp, tmp))) return bail(rc);
 #define ING(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, F2Q_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); return bail(F2Q_EHIP); } } while (0)
     ING(hipMemsetAsync(d_text + nbytes, 0, padded - nbytes, c->stream));
+    const double tc0 = now_ms();
     ING(hipMemcpyAsync(d_text, fastq, nbytes, hipMemcpyHostToDevice, c->stream));
+    if (c->trace) { ING(hipStreamSynchronize(c->stream)); c->tr_copy += now_ms() - tc0; }
     hipLaunchKernelGGL(k_nl_count, dim3(n_chunks), dim3(256), 0, c->stream, d_text, (uint64_t)nbytes, d_cc);
     ING(hipGetLastError());
     size_t cub_bytes = 0;
@@ -648,7 +692,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     const uint32_t sentinel = (uint32_t)nbytes + 1u;
     ING(hipMemcpyAsync(d_ls + n_newlines + 1, &sentinel, 4, hipMemcpyHostToDevice, c->stream));
     b->n_reads = n_rec;
-    if (n_rec == 0) { ING(hipStreamSynchronize(c->stream)); free_all(tmp); *out = b; return F2Q_OK; }
+    if (n_rec == 0) { ING(hipStreamSynchronize(c->stream)); free_all(c, tmp); *out = b; return F2Q_OK; }
     // bytes consumed: the start of line 4*n_rec, or everything when the last record's last line is unterminated
     uint32_t cons32 = (uint32_t)nbytes;
     if ((uint64_t)4 * n_rec <= n_newlines) ING(hipMemcpyAsync(&cons32, d_ls + (size_t)4 * n_rec, 4, hipMemcpyDeviceToHost, c->stream));
@@ -705,7 +749,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     ING(hipGetLastError());
     ING(hipStreamSynchronize(c->stream));             // scratch dies with this frame
 #undef ING
-    free_all(tmp);
+    free_all(c, tmp);
     *out = b;
     return F2Q_OK;
 }
@@ -875,8 +919,8 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
     reader.join();
     drop();
     if (t) *t = sum;
-    if (c->trace) fprintf(stderr, "[f2q trace] %s (%s, %d io threads): pinned %.1f ms, reader busy %.1f ms, waited for reader %.1f ms, frame+pack %.1f ms, count %.1f ms, free %.1f ms\n",
-                          path, src.kind_name(), src.n_threads, tr_b - tr_a, read_ms, wait_ms, c->tr_frame, c->tr_count, c->tr_free);
+    if (c->trace) fprintf(stderr, "[f2q trace] %s (%s, %d io threads): pinned %.1f ms, reader busy %.1f ms, waited for reader %.1f ms, frame+pack %.1f ms (H2D copy %.1f), count %.1f ms, free %.1f ms\n",
+                          path, src.kind_name(), src.n_threads, tr_b - tr_a, read_ms, wait_ms, c->tr_frame, c->tr_copy, c->tr_count, c->tr_free);
     if (rc) return rc;
     if (src.truncated()) return fail(c, F2Q_ETRUNCATED, std::string(path) + " is an incomplete or corrupted gzip file");
     return F2Q_OK;
@@ -1041,7 +1085,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
         b->rb.first_index = 0;
         b->dev_bytes += g * (uint64_t)(2 * R + 20);
     } while (0);
-    if (rc) { free_all(b->allocs); delete b; return rc; }
+    if (rc) { free_all(c, b->allocs); delete b; return rc; }
     *out = b;
     return F2Q_OK;
 }
