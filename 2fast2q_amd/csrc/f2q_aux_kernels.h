@@ -15,12 +15,11 @@ __global__ void k_ec_rehash(EcDev old, unsigned long long n_old, EcDev nw)
     for (uint32_t k = 0; k < len; k++) { h ^= (src[k >> 2] >> (8 * (k & 3))) & 0xFFu; h *= 1099511628211ull; }
     h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
     const unsigned long long fp = (h >> 32) & 0xFFFFFFFFull;
-    // keys are distinct, so plain claim-by-CAS of an empty slot is enough
-    unsigned long long ne = atomicAdd(&nw.ctr[0], 1ull);
-    unsigned long long off = atomicAdd(&nw.ctr[1], (unsigned long long)nwords);
-    for (int w = 0; w < nwords; w++) nw.arena[off + w] = src[w];
-    nw.ent_off[ne] = off; nw.ent_len[ne] = len;
-    nw.ent_count[ne] = old.ent_count[e]; nw.ent_first[ne] = old.ent_first[e];
+    // entries keep their number and their place in the arena (the host copies both wholesale and sets the counters:
+    // a device-wide counter bumped per key is one address for everybody); only the slots are re-derived.  Keys are
+    // distinct, so plain claim-by-CAS of an empty slot is enough
+    const unsigned long long ne = e;
+    (void)nwords;
     uint32_t s = (uint32_t)h & nw.mask;
     for (;;) {
         unsigned long long prev = atomicCAS(&nw.slots[s], 0ull, (fp << 32) | (ne + 1ull));
@@ -43,7 +42,6 @@ __global__ void k_ec64_rehash(EcDev old, EcDev nw)
         s = (s + 1) & nw.k64_mask;
     }
     nw.k64_count[s] = old.k64_count[i]; nw.k64_first[s] = old.k64_first[i];
-    atomicAdd(&nw.ctr[3], 1ull);
 }
 
 // ---- synthetic workload, device side ----------------------------------------------------------

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const FixedGeom g = fixed_geom(run);
     unsigned long long st[5] = {0, 0, 0, 0, 0};
+    uint32_t n_new = 0;                       // keys this lane put into the table
     for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
         const uint32_t tile = base + wave;
         if (tile >= pb.n_tiles) continue;
@@ -347,10 +348,11 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev 
             if (L < 0) L = 0;
             const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + 4u * lane + (uint32_t)j;
-            ec64_insert(ec, key, L, read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
+            n_new += ec64_insert_n(ec, key, L, read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
             st[1]++;
         }
     }
+    ec64_report_new(ec, n_new);
     __shared__ unsigned long long st_lds[8];
     flush_stats(acc, st, st_lds, nullptr);
 }
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     const int pk_len = (int)lib.pk.len;
     const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
     unsigned long long st[5] = {0, 0, 0, 0, 0};
+    uint32_t n_new = 0;                       // Extract+Count: keys this lane put into the single-word table
 #ifdef F2Q_STAMP
     unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t0_, t1_;
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
             } else {
                 const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
                 st[0]++;
-                if (EC) { ec64_insert(ec, key, L, gi); st[1]++; }
+                if (EC) { n_new += ec64_insert_n(ec, key, L, gi); st[1]++; }
                 else if (L == pk_len) {
                     const int e = packed_exact(lib, key);
                     if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
@@ -575,6 +578,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
 #ifdef F2Q_STAMP
     if (lane == 0 && acc.stamp) for (int i = 0; i < 4; i++) atomicAdd(&acc.stamp[i], tp[i]);
 #endif
+    if (EC) ec64_report_new(ec, n_new);
     __shared__ unsigned long long st_lds[8];
     flush_stats(acc, st, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
     if (USE_LDS && !EC) {

@@ -400,10 +400,13 @@ F2Q_HD uint64_t key_hash(const KV &kv)
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define F2Q_LD64(p) __hip_atomic_load(gpw(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define F2Q_LD32(p) __hip_atomic_load(gpw(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define F2Q_ST64(p, v) __hip_atomic_store(gpw(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define F2Q_ST32(p, v) __hip_atomic_store(gpw(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#ifndef F2Q_EC_SCOPE
+#define F2Q_EC_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+#define F2Q_LD64(p) __hip_atomic_load(gpw(p), __ATOMIC_RELAXED, F2Q_EC_SCOPE)
+#define F2Q_LD32(p) __hip_atomic_load(gpw(p), __ATOMIC_RELAXED, F2Q_EC_SCOPE)
+#define F2Q_ST64(p, v) __hip_atomic_store(gpw(p), (v), __ATOMIC_RELAXED, F2Q_EC_SCOPE)
+#define F2Q_ST32(p, v) __hip_atomic_store(gpw(p), (v), __ATOMIC_RELAXED, F2Q_EC_SCOPE)
 #else
 #define F2Q_LD64(p) (*(p))
 #define F2Q_LD32(p) (*(p))
@@ -414,7 +417,7 @@ F2Q_HD uint64_t key_hash(const KV &kv)
 F2Q_HD unsigned long long ec_cas(unsigned long long *p, unsigned long long cmp, unsigned long long val)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_compare_exchange_strong(gpw(p), &cmp, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_compare_exchange_strong(gpw(p), &cmp, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, F2Q_EC_SCOPE);
     return cmp;
 #else
     unsigned long long old = *p; if (old == cmp) *p = val; return old;
@@ -423,7 +426,7 @@ F2Q_HD unsigned long long ec_cas(unsigned long long *p, unsigned long long cmp, 
 F2Q_HD unsigned long long ec_fetch_add(unsigned long long *p, unsigned long long v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_fetch_add(gpw(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_fetch_add(gpw(p), v, __ATOMIC_RELAXED, F2Q_EC_SCOPE);
 #else
     unsigned long long old = *p; *p += v; return old;
 #endif
@@ -431,7 +434,7 @@ F2Q_HD unsigned long long ec_fetch_add(unsigned long long *p, unsigned long long
 F2Q_HD void ec_min(unsigned long long *p, unsigned long long v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_fetch_min(gpw(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_min(gpw(p), v, __ATOMIC_RELAXED, F2Q_EC_SCOPE);
 #else
     if (v < *p) *p = v;
 #endif
@@ -503,26 +506,47 @@ F2Q_HD void ec_insert(const EcDev &ec, const KV &kv, unsigned long long read_ind
     F2Q_ST64(&ec.ctr[2], 2ull);                         // probe bound hit: reported as an error
 }
 
-// single-word insert-or-increment for regular keys (see EcDev)
-F2Q_HD void ec64_insert(const EcDev &ec, uint64_t key, int len, unsigned long long read_index)
+// single-word insert-or-increment for regular keys (see EcDev); returns 1 when the key is new.  The number of keys
+// (ctr[3], read by the host between launches only) is NOT bumped here: a counter every new key increments is one
+// address for the whole device, and 0.6 M same-address atomics cost ~9 ms — callers add up their new keys and
+// report them once per wave (ec64_report_new).
+F2Q_HD uint32_t ec64_insert_n(const EcDev &ec, uint64_t key, int len, unsigned long long read_index)
 {
     const unsigned long long k = ((unsigned long long)len << 58) | key;
     uint32_t s = hash32(k ^ (k >> 29), 32) & ec.k64_mask;
     for (uint32_t guard = 0; guard <= ec.k64_mask; guard++) {
         unsigned long long v = F2Q_LD64(&ec.k64_slots[s]);
+        uint32_t fresh = 0;
         if (v == KEY_EMPTY) {
             v = ec_cas(&ec.k64_slots[s], KEY_EMPTY, k);
-            if (v == KEY_EMPTY) { ec_fetch_add(&ec.ctr[3], 1ull); v = k; }
+            if (v == KEY_EMPTY) { fresh = 1; v = k; }
         }
         if (v == k) {
             ec_fetch_add(&ec.k64_count[s], 1ull);
             // the minimum only ever decreases: a plain look first saves the read-modify-write for almost every read
             if (read_index < F2Q_LD64(&ec.k64_first[s])) ec_min(&ec.k64_first[s], read_index);
-            return;
+            return fresh;
         }
         s = (s + 1) & ec.k64_mask;
     }
     F2Q_ST64(&ec.ctr[2], 3ull);                          // table full: reported as an error by the host
+    return 0;
+}
+// one lane at a time (general path, host twin): report immediately
+F2Q_HD void ec64_insert(const EcDev &ec, uint64_t key, int len, unsigned long long read_index)
+{
+    if (ec64_insert_n(ec, key, len, read_index)) ec_fetch_add(&ec.ctr[3], 1ull);
+}
+// every lane of the wave calls this once, after its last insert
+F2Q_HD void ec64_report_new(const EcDev &ec, uint32_t n_new)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
+    if ((threadIdx.x & 63u) == 0 && n_new) ec_fetch_add(&ec.ctr[3], (unsigned long long)n_new);
+#else
+    ec.ctr[3] += n_new;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

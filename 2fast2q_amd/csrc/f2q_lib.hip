@@ -36,6 +36,7 @@ struct f2q_block {
     RawBlock rb{};
     std::vector<void *> allocs;
     uint64_t n_reads = 0, n_general = 0, dev_bytes = 0;
+    uint64_t raw_key_bytes = 0;            // upper bound of the key bytes the raw records can produce (Extract+Count arena sizing)
 };
 
 struct f2q_ctx {
@@ -84,7 +85,8 @@ struct f2q_ctx {
     std::string err;
     // F2Q_TRACE=1: wall-clock split of the host entry points, printed by f2q_count_file (diagnostics only)
     bool trace = false;
-    double tr_frame = 0, tr_count = 0, tr_free = 0, tr_copy = 0;
+    double tr_frame = 0, tr_count = 0, tr_free = 0, tr_copy = 0, tr_malloc = 0, tr_hipfree = 0, tr_reserve = 0;
+    uint64_t n_malloc = 0, n_hipfree = 0, n_reuse = 0, n_rehash = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -109,10 +111,13 @@ static int dev_get(f2q_ctx *c, size_t bytes, void **out)
     auto it = c->dev_idle.lower_bound(bytes);
     if (it != c->dev_idle.end() && it->first <= bytes + bytes / 4 + (64 << 10)) {
         *out = it->second; c->dev_idle_bytes -= it->first; c->dev_idle.erase(it);
+        c->n_reuse++;
         return F2Q_OK;
     }
     void *p = nullptr;
+    const double m0 = now_ms();
     hipError_t e = hipMalloc(&p, bytes);
+    c->tr_malloc += now_ms() - m0; c->n_malloc++;
     if (e != hipSuccess && !c->dev_idle.empty()) {           // give the idle memory back and retry once
         for (auto &kv : c->dev_idle) { c->dev_size.erase(kv.second); (void)hipFree(kv.second); }
         c->dev_idle.clear(); c->dev_idle_bytes = 0;
@@ -158,7 +163,9 @@ static void free_all(f2q_ctx *c, std::vector<void *> &v)
             c->dev_idle.emplace(it->second, p); c->dev_idle_bytes += it->second;
         } else {
             if (it != c->dev_size.end()) c->dev_size.erase(it);
+            const double f0 = now_ms();
             (void)hipFree(p);
+            c->tr_hipfree += now_ms() - f0; c->n_hipfree++;
         }
     }
     v.clear();
@@ -238,6 +245,7 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     c->device = p->device;
     { const char *fv = getenv("F2Q_FORCE_V1"); c->force_v1 = fv && fv[0] == '1'; }
     { const char *tr = getenv("F2Q_TRACE"); c->trace = tr && tr[0] == '1'; }
+    { const char *dc = getenv("F2Q_DEV_CACHE_MB"); if (dc && atol(dc) >= 0) c->dev_idle_cap = (size_t)atol(dc) << 20; }
     { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_HOST_PACK"); c->host_pack = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_FORCE_GENERAL"); c->force_general = fv && fv[0] == '1'; }
@@ -275,6 +283,8 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->trace) fprintf(stderr, "[f2q trace] device memory: %llu hipMalloc %.1f ms, %llu hipFree %.1f ms, %llu reused; Extract+Count reserve %.1f ms (%llu rehashes)\n",
+                          (unsigned long long)c->n_malloc, c->tr_malloc, (unsigned long long)c->n_hipfree, c->tr_hipfree, (unsigned long long)c->n_reuse, c->tr_reserve, (unsigned long long)c->n_rehash);
     free_all(c, c->lib_allocs); free_all(c, c->ec_allocs);
     for (auto &kv : c->dev_idle) (void)hipFree(kv.second);
     c->dev_idle.clear(); c->dev_size.clear();
@@ -385,17 +395,36 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
     if (c->ec.slots) {
         HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
+        if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error)");
     }
     // both tables are sized for "every read brings a new key": slots = 2 * max_entries
     const uint64_t need_e = std::max(ctr[0], ctr[3]) + reads + 16, need_w = ctr[1] + (key_bytes + 3) / 4 + reads + 16;
     if (c->ec.slots && need_e <= c->ec.max_entries && need_w <= c->ec.arena_words) return F2Q_OK;
-    uint64_t ne = std::max<uint64_t>(need_e * 2, 1u << 16), nw = std::max<uint64_t>(need_w * 2, 1u << 18);
+    // growth doubles the room of the keys already there (amortised rehash), not the head room of one launch
+    uint64_t ne = std::max<uint64_t>(need_e + std::max<uint64_t>(std::max(ctr[0], ctr[3]), reads / 2), 1u << 16);
+    uint64_t nw = std::max<uint64_t>(need_w + std::max<uint64_t>(ctr[1], key_bytes / 16), 1u << 18);
+    const double rs0 = now_ms();
+    if (c->ec.slots && (ctr[0] || ctr[3])) {
+        c->n_rehash++;
+        if (c->trace && c->n_rehash <= 4)
+            fprintf(stderr, "[f2q trace] Extract+Count tables grow: keys %llu/%llu, entries needed %llu of %u, arena words needed %llu of %llu\n",
+                    ctr[0], ctr[3], (unsigned long long)need_e, c->ec.max_entries, (unsigned long long)need_w, c->ec.arena_words);
+    }
     EcDev fresh; std::vector<void *> owner;
     int rc = ec_alloc(c, fresh, owner, ne, nw);
     if (rc) { free_all(c, owner); return rc; }
     if (c->ec.slots && ctr[0]) {
+        HIPC(c, hipMemcpyAsync(fresh.arena, c->ec.arena, ctr[1] * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(fresh.ent_off, c->ec.ent_off, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(fresh.ent_len, c->ec.ent_len, ctr[0] * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(fresh.ent_count, c->ec.ent_count, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(fresh.ent_first, c->ec.ent_first, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
         hipLaunchKernelGGL(k_ec_rehash, dim3((unsigned)((ctr[0] + 255) / 256)), dim3(256), 0, c->stream, c->ec, ctr[0], fresh);
         HIPC(c, hipGetLastError());
+    }
+    if (c->ec.slots) {
+        const unsigned long long carried[4] = {ctr[0], ctr[1], 0ull, ctr[3]};
+        HIPC(c, hipMemcpyAsync(fresh.ctr, carried, sizeof carried, hipMemcpyHostToDevice, c->stream));
     }
     if (c->ec.slots && ctr[3]) {
         hipLaunchKernelGGL(k_ec64_rehash, dim3((unsigned)(((uint64_t)c->ec.k64_mask + 256) / 256)), dim3(256), 0, c->stream, c->ec, fresh);
@@ -404,33 +433,20 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
     HIPC(c, hipStreamSynchronize(c->stream));
     free_all(c, c->ec_allocs);
     c->ec_allocs = owner; c->ec = fresh;
+    c->tr_reserve += now_ms() - rs0;
     return F2Q_OK;
 }
 
 // ---- launching ----------------------------------------------------------------------------------
-static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
+// one set of launches over a view of a block (all of it in Counter mode, a step of it in Extract+Count mode)
+static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, Accum &acc, uint32_t &launches)
 {
-    if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
-    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr, nullptr, nullptr};
-#ifdef F2Q_STAMP
-    static unsigned long long *stamp_d = nullptr;
-    if (!stamp_d) { (void)hipMalloc((void **)&stamp_d, 64); (void)hipMemset(stamp_d, 0, 64); }
-    acc.stamp = stamp_d;
-#endif
-    if (c->prm.mode == 1 && b->n_reads) {
-        // worst case every read inserts a new key made of all its windows
-        uint64_t key_bytes = b->dev_bytes;   // upper bound: no key is longer than the read's bytes + separators
-        int rc = ec_reserve(c, b->n_reads, key_bytes + (uint64_t)b->n_reads * F2Q_MAX_ITER);
-        if (rc) return rc;
-    }
-    uint32_t launches = 0;
-    HIPC(c, hipEventRecord(c->ev_k0, c->stream));
-    if (b->pb.n_tiles && b->pb.planar_nw) {
+    if (pb.n_tiles && pb.planar_nw) {
         // packed anchored path
         const bool ecm = c->prm.mode == 1;
         const bool lds = !ecm && c->lib_h.n_features <= F2Q_HIST_MAX;
         uint32_t an_mult = 4u; { const char *e = getenv("F2Q_AN_GRID"); if (e && atoi(e) > 0) an_mult = (uint32_t)atoi(e); }
-        const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * an_mult);
+        const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * an_mult);
         const size_t shmem = (size_t)F2Q_AN_WAVES * F2Q_AN_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
         if (!ecm) {
             const size_t need = lds ? (size_t)grid * c->lib_h.n_features : 0;
@@ -444,17 +460,17 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             }
             if (lds) { acc.slab = c->slab_d; acc.stat_slab = c->stat_slab_d; }
         }
-        const int nw = (int)b->pb.planar_nw, kb = c->plan.kb;
+        const int nw = (int)pb.planar_nw, kb = c->plan.kb;
         const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
 #define F2Q_LAUNCH_AN2(NW_, KB_, SQ_)                                                                                \
         do {                                                                                                         \
             if (ecm) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, true, false, SQ_>), dim3(grid), dim3(F2Q_AN_THREADS),   \
-                                        shmem, c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);     \
+                                        shmem, c->stream, c->run_d, c->lib_d, c->ec, pb, acc, c->reads_seen);     \
             else if (lds) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, true, SQ_>), dim3(grid),               \
                                              dim3(F2Q_AN_THREADS), shmem, c->stream, c->run_d, c->lib_d, c->ec,      \
-                                             b->pb, acc, c->reads_seen);                                             \
+                                             pb, acc, c->reads_seen);                                             \
             else hipLaunchKernelGGL((k_count_anchor<NW_, KB_, false, false, SQ_>), dim3(grid), dim3(F2Q_AN_THREADS),  \
-                                    shmem, c->stream, c->run_d, c->lib_d, c->ec, b->pb, acc, c->reads_seen);         \
+                                    shmem, c->stream, c->run_d, c->lib_d, c->ec, pb, acc, c->reads_seen);         \
         } while (0)
 #define F2Q_LAUNCH_AN(NW_, KB_) do { if (sameq) F2Q_LAUNCH_AN2(NW_, KB_, true); else F2Q_LAUNCH_AN2(NW_, KB_, false); } while (0)
         if (nw == 3 && kb == 0) F2Q_LAUNCH_AN(3, 0);
@@ -473,18 +489,18 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             HIPC(c, hipGetLastError());
             launches++;
         }
-    } else if (b->pb.n_tiles && c->prm.mode == 1) {
-        const uint32_t wgs = (b->pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
+    } else if (pb.n_tiles && c->prm.mode == 1) {
+        const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
         const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 4u);
-        hipLaunchKernelGGL(k_extract_fixed4, dim3(grid), dim3(F2Q_V2_THREADS), 0, c->stream, c->run_d, c->ec, b->pb, acc, c->reads_seen);
+        hipLaunchKernelGGL(k_extract_fixed4, dim3(grid), dim3(F2Q_V2_THREADS), 0, c->stream, c->run_d, c->ec, pb, acc, c->reads_seen);
         HIPC(c, hipGetLastError());
         launches++;
-    } else if (b->pb.n_tiles) {
+    } else if (pb.n_tiles) {
         const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
         const bool v2 = !c->force_v1 && c->lib_h.pk.len == (uint32_t)c->run_h.length && c->lib_h.pk.len > 0 &&
                         c->lib_h.n_irregular == 0;
         if (v2) {
-            const uint32_t wgs = (b->pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
+            const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
             const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 4);
             const FixedGeom fg = fixed_geom(c->run_h);
@@ -509,20 +525,20 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
                 acc.stat_slab = c->stat_slab_d;
             }
             if (!lds) {
-                if (b->pb.n_slots > c->hit_buf_n) {
+                if (pb.n_slots > c->hit_buf_n) {
                     if (c->hit_buf_d) (void)hipFree(c->hit_buf_d);
                     c->hit_buf_d = nullptr; c->hit_buf_n = 0;
-                    HIPC(c, hipMalloc((void **)&c->hit_buf_d, b->pb.n_slots * sizeof(uint32_t)));
-                    c->hit_buf_n = b->pb.n_slots;
+                    HIPC(c, hipMalloc((void **)&c->hit_buf_d, pb.n_slots * sizeof(uint32_t)));
+                    c->hit_buf_n = pb.n_slots;
                 }
-                HIPC(c, hipMemsetAsync(c->hit_buf_d, 0xFF, b->pb.n_slots * sizeof(uint32_t), c->stream));
+                HIPC(c, hipMemsetAsync(c->hit_buf_d, 0xFF, pb.n_slots * sizeof(uint32_t), c->stream));
                 acc.hit_buf = c->hit_buf_d;
             }
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, b->pb, acc);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, pb, acc);
             HIPC(c, hipGetLastError());
             if (!lds && nf_) {
                 hipLaunchKernelGGL(k_hist_ranges, dim3(n_ranges * n_parts), dim3(1024), (size_t)F2Q_HIST_MAX * 4, c->stream,
-                                   c->hit_buf_d, (uint64_t)b->pb.n_slots, nf_, n_parts, c->slab_d);
+                                   c->hit_buf_d, (uint64_t)pb.n_slots, nf_, n_parts, c->slab_d);
                 HIPC(c, hipGetLastError());
                 launches++;
             }
@@ -532,25 +548,76 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
                 launches++;
             }
         } else {
-            const uint32_t grid = std::min<uint32_t>(b->pb.n_tiles, (uint32_t)c->n_cu * 8u);
+            const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * 8u);
             if (lds) {
                 size_t shmem = std::max<size_t>(4, (size_t)c->lib_h.n_features * 4);
-                hipLaunchKernelGGL(k_count_fixed<true>, dim3(grid), dim3(F2Q_TILE), shmem, c->stream, c->run_d, c->lib_d, b->pb, acc);
+                hipLaunchKernelGGL(k_count_fixed<true>, dim3(grid), dim3(F2Q_TILE), shmem, c->stream, c->run_d, c->lib_d, pb, acc);
             } else {
-                hipLaunchKernelGGL(k_count_fixed<false>, dim3(grid), dim3(F2Q_TILE), 0, c->stream, c->run_d, c->lib_d, b->pb, acc);
+                hipLaunchKernelGGL(k_count_fixed<false>, dim3(grid), dim3(F2Q_TILE), 0, c->stream, c->run_d, c->lib_d, pb, acc);
             }
         }
         HIPC(c, hipGetLastError());
         launches++;
     }
-    if (b->rb.n) {
-        RawBlock rb = b->rb;
+    if (rbv.n) {
+        RawBlock rb = rbv;
         rb.first_index += c->reads_seen;
         const uint64_t wg = (rb.n + 255) / 256;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(wg, (uint64_t)c->n_cu * 16u);
         hipLaunchKernelGGL(k_count_general, dim3(grid), dim3(256), 0, c->stream, c->run_d, c->lib_d, c->ec, rb, acc);
         HIPC(c, hipGetLastError());
         launches++;
+    }
+    return F2Q_OK;
+}
+
+static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
+{
+    if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
+    Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr, nullptr, nullptr};
+#ifdef F2Q_STAMP
+    static unsigned long long *stamp_d = nullptr;
+    if (!stamp_d) { (void)hipMalloc((void **)&stamp_d, 64); (void)hipMemset(stamp_d, 0, 64); }
+    acc.stamp = stamp_d;
+#endif
+    uint32_t launches = 0;
+    HIPC(c, hipEventRecord(c->ev_k0, c->stream));
+    if (c->prm.mode == 0) {
+        int rc = launch_view(c, b->pb, b->rb, acc, launches);
+        if (rc) return rc;
+    } else if (b->n_reads) {
+        // Extract+Count: the tables must have room for "every read of the launch is a new key".  Sizing them for the
+        // whole block (50 M reads -> 2^28 slots) makes the table many GiB and every probe a DRAM access, so the block
+        // is walked in steps of F2Q_EC_STEP reads: room for one step beyond the keys already there is enough, and the
+        // tables grow (device rehash) only when the number of distinct keys does.
+        uint64_t step = (uint64_t)8 << 20;
+        { const char *e = getenv("F2Q_EC_STEP"); if (e && atol(e) >= F2Q_TILE) step = (uint64_t)atol(e); }
+        const uint32_t tiles_per = (uint32_t)std::max<uint64_t>(1, step / F2Q_TILE);
+        const RawBlock none{};
+        for (uint32_t t0 = 0; t0 < b->pb.n_tiles; t0 += tiles_per) {
+            PackedBlock v = b->pb;
+            const uint32_t nt = std::min<uint32_t>(tiles_per, b->pb.n_tiles - t0);
+            v.n_tiles = nt; v.n_slots = (uint64_t)nt * F2Q_TILE;
+            v.bases += (size_t)t0 * v.wb * F2Q_TILE; v.qual += (size_t)t0 * v.wq * F2Q_TILE;
+            if (v.len) v.len += (size_t)t0 * F2Q_TILE;
+            if (v.index) v.index += (size_t)t0 * F2Q_TILE; else v.first_index += (uint64_t)t0 * F2Q_TILE;
+            // packed reads give single-window keys of at most rmax bytes
+            int rc = ec_reserve(c, v.n_slots, v.n_slots * ((uint64_t)v.rmax + F2Q_MAX_ITER));
+            if (rc) return rc;
+            if ((rc = launch_view(c, v, none, acc, launches))) return rc;
+        }
+        const PackedBlock nop{};
+        for (uint64_t r0 = 0; r0 < b->rb.n; r0 += step) {
+            RawBlock v = b->rb;
+            v.n = std::min<uint64_t>(step, b->rb.n - r0);
+            v.off += r0; v.len += r0; v.qlen += r0;
+            if (v.qoff) v.qoff += r0;
+            if (v.index) v.index += r0; else v.first_index += r0;
+            // no key is longer than its record's bytes + separators (block-wide bound: the arena is never cleared)
+            int rc = ec_reserve(c, v.n, b->raw_key_bytes + v.n * F2Q_MAX_ITER);
+            if (rc) return rc;
+            if ((rc = launch_view(c, nop, v, acc, launches))) return rc;
+        }
     }
     HIPC(c, hipEventRecord(c->ev_k1, c->stream));
     c->reads_seen += b->n_reads;
@@ -641,6 +708,7 @@ static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_bloc
             if ((rc = dev_upload(c, hp.g_index.data(), hp.g_index.size(), &dix, b->allocs))) break;
             b->rb.n = hp.g_len.size(); b->rb.raw = dr; b->rb.off = doff; b->rb.len = dlen; b->rb.qlen = dqlen; b->rb.index = dix;
             b->dev_bytes += hp.raw.size() + hp.g_len.size() * 20;
+            b->raw_key_bytes = hp.raw.size();
         }
         hipError_t e = hipStreamSynchronize(c->stream);      // host staging vectors die with this frame
         if (e != hipSuccess) { rc = fail(c, F2Q_EHIP, hipGetErrorString(e)); break; }
@@ -742,7 +810,8 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
         if ((rc = dev_alloc(c, (size_t)n_dirty, &o.g_index, b->allocs))) return bail(rc);
         b->rb.n = n_dirty; b->rb.raw = d_text; b->rb.off = o.g_off; b->rb.qoff = o.g_qoff; b->rb.len = o.g_len;
         b->rb.qlen = o.g_qlen; b->rb.index = o.g_index;
-        b->dev_bytes += nbytes;                       // upper bound of the key bytes an Extract+Count run can add
+        b->dev_bytes += nbytes;
+        b->raw_key_bytes = nbytes;                    // the records point into the text: no key is longer than its record
     }
     b->n_general = n_dirty;
     hipLaunchKernelGGL(k_pack, dim3(rgrid), dim3(256), 0, c->stream, ing, c->plan, d_before, o);
@@ -1084,6 +1153,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
         b->rb.n = g; b->rb.raw = o.raw; b->rb.off = o.off; b->rb.len = o.glen; b->rb.qlen = o.gqlen; b->rb.index = o.gindex;
         b->rb.first_index = 0;
         b->dev_bytes += g * (uint64_t)(2 * R + 20);
+        b->raw_key_bytes = g * (uint64_t)R;
     } while (0);
     if (rc) { free_all(c, b->allocs); delete b; return rc; }
     *out = b;
