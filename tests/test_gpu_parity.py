@@ -249,6 +249,32 @@ def test_ec_table_growth_across_blocks(P):
         assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
 
 
+@pytest.mark.parametrize("step", ["256", "2048", "100000"])
+@pytest.mark.parametrize("fixed", [False, True], ids=["anchored", "fixed_window"])
+def test_ec_block_walked_in_steps(P, monkeypatch, step, fixed):
+    """Extract+Count walks a block in steps of F2Q_EC_STEP reads (tables sized for one step beyond the keys they hold,
+    grown by device rehash in between): tiny steps = many launches and many rehashes inside ONE block, same result,
+    same first-seen order"""
+    monkeypatch.setenv("F2Q_EC_STEP", step)
+    guides = synth.make_library(5000, 20, 41)
+    if fixed:
+        kw = dict(mode="EC", start="10", length=20)
+        fq = synth.make_fastq(synth.Spec(seed=77, n_reads=60000, read_len=80, start=10, p_rand=0.4), guides)
+    else:
+        kw = dict(mode="EC", upstream=UP, downstream=DOWN, miss_search_up=1)
+        with P.Counter(features=guides, miss=1) as gen:
+            fq = bytes(gen.synth_fastq(seed=9, n_reads=60000, read_len=150, cassette=True, up=UP, down=DOWN, p_rand=0.4))
+    fq = sprinkle_symbols(fq, 5, rate=0.003)                  # raw records + byte-string keys in the same run
+    orc = O.Oracle(**kw)
+    orc.count_fastq(fq)
+    with P.Counter(**kw) as c:
+        _, t = c.count_block(fq, want_timing=True)
+        _, stats = c.read_counts()
+        assert list(stats) == orc.stats()
+        assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+        assert t["launches"] >= 60000 // int(step)
+
+
 @pytest.mark.parametrize("anchors", ["both", "up", "down"])
 def test_packed_anchor_with_odd_symbols_gpu(P, anchors):
     guides = synth.make_library(120, 16, 31337)
