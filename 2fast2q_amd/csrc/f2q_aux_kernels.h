@@ -94,8 +94,10 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
         if ((p & 31) == 0) fw = rnd(s.seed, i, F_FLANK0 + (p >> 5));
         uint8_t c = synth_base(s, r, p, fw);
         uint32_t code = base_code(c); if (code > 3u) code = 0;
-        qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * (p & 3));
-        if ((p & 3) == 3 || p == R - 1) { qp[(uint64_t)(p >> 2) * F2Q_TILE] = qw; qw = 0; }
+        if (!o.planar_nw) {
+            qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * (p & 3));
+            if ((p & 3) == 3 || p == R - 1) { qp[(uint64_t)(p >> 2) * F2Q_TILE] = qw; qw = 0; }
+        }
         if (o.planar_nw) {                       // anchored runs: bit-planes, 32 bases per word
             lw |= (code & 1u) << (p & 31); hw |= (code >> 1) << (p & 31);
             if ((p & 31) == 31 || p == R - 1) {
@@ -105,6 +107,17 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
         } else {
             bw |= code << (2 * (p & 15));
             if ((p & 15) == 15 || p == R - 1) { bp[(uint64_t)(p >> 4) * F2Q_TILE] = bw; bw = 0; }
+        }
+    }
+    if (o.planar_nw) {                           // quality bytes of planar tiles: transposed 32-base groups (planar_qpos)
+        const uint32_t nq = 8u * (((uint32_t)R + 31u) / 32u);
+        for (uint32_t w = 0; w < nq; w++) {
+            uint32_t v = 0;
+            for (uint32_t j = 0; j < 4; j++) {
+                const int p = (int)planar_qpos(w, j);
+                if (p < R) v |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * j);
+            }
+            qp[(uint64_t)w * F2Q_TILE] = v;
         }
     }
 }

@@ -381,7 +381,7 @@ __device__ __noinline__ void anchor_slow(const RunDev *run, const LibDev *lib, c
     for (int i = 0; i < r; i++) {
         const uint32_t lo = bp[(uint64_t)(i >> 5) * F2Q_TILE], hi = bp[(uint64_t)(nw + (i >> 5)) * F2Q_TILE];
         seq[i] = (uint8_t)"ACGT"[((lo >> (i & 31)) & 1u) | (((hi >> (i & 31)) & 1u) << 1)];
-        qual[i] = (uint8_t)((qp[(uint64_t)(i >> 2) * F2Q_TILE] >> (8 * (i & 3))) & 0xFFu);
+        qual[i] = (uint8_t)((qp[(uint64_t)planar_qword((uint32_t)i) * F2Q_TILE] >> (8 * planar_qbyte((uint32_t)i))) & 0xFFu);
         if (qual[i] & 0x80u) { seq[i] = (uint8_t)'N'; qual[i] &= 0x7Fu; }      // flagged: a symbol that equals nothing
     }
     general_read<const uint8_t *>(*run, *lib, *ec, *acc, seq, r, qual, r, read_index, st);
@@ -456,7 +456,17 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
         // the scheduling barrier keeps the compiler from stretching their live ranges into the anchor search.
         uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW], FLG[NW];
         const bool flagged = (l != F2Q_LEN_SKIP) && (l & F2Q_LEN_FLAG);
-        {
+        if (__ballot(flagged) == 0ull) {              // the usual tile: no flag bits to strip, no flag planes to build
+#pragma unroll
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q8[i] = Q[8 * cw + i];
+                FW[cw] = fail_word8<false>(q8, ah_w);
+                if (!SAMEQ) { FU[cw] = fail_word8<false>(q8, ah_u); FD[cw] = fail_word8<false>(q8, ah_d); }
+                FLG[cw] = 0u;
+            }
+        } else {
 #pragma unroll
             for (int cw = 0; cw < NW; cw++) {
                 uint32_t q8[8];
@@ -668,14 +678,16 @@ __global__ __launch_bounds__(256) void k_count_general(const RunDev *__restrict_
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
     unsigned long long st[5] = {0, 0, 0, 0, 0};
+    uint32_t n_new = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rb.n;
          i += (uint64_t)gridDim.x * blockDim.x) {
         gbytes seq = gp(rb.raw) + gp(rb.off)[i];
         const int r = (int)gp(rb.len)[i], qn = (int)gp(rb.qlen)[i];
         gbytes qual = rb.qoff ? gp(rb.raw) + gp(rb.qoff)[i] : seq + r;
         const unsigned long long gi = rb.first_index + (rb.index ? gp(rb.index)[i] : i);
-        general_read(run, lib, ec, acc, seq, r, qual, qn, gi, st);
+        general_read(run, lib, ec, acc, seq, r, qual, qn, gi, st, &n_new);
     }
+    if (run.mode == 1) ec64_report_new(ec, n_new);
     __shared__ unsigned long long st_lds[8];
     flush_stats(acc, st, st_lds, nullptr);
 }

@@ -555,7 +555,7 @@ F2Q_HD void ec64_report_new(const EcDev &ec, uint32_t n_new)
 template <class P>
 F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, const Accum &acc,
                          P seq, int r, P qual, int qn,
-                         unsigned long long read_index, unsigned long long st[5])
+                         unsigned long long read_index, unsigned long long st[5], uint32_t *n_new = nullptr)
 {
     KeyViewT<P> kv; kv.seq = seq; kv.nseg = 0; kv.len = 0;
     bool all_failed = true;
@@ -589,7 +589,9 @@ F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, 
                 if (c > 3u) regular = false;
                 key |= (uint64_t)(c & 3u) << (2 * j);
             }
-            if (regular) ec64_insert(ec, key, kv.len, read_index);
+            // n_new: the caller sums new single-word keys and reports them once per wave (ec64_report_new)
+            if (regular && n_new) *n_new += ec64_insert_n(ec, key, kv.len, read_index);
+            else if (regular) ec64_insert(ec, key, kv.len, read_index);
             else ec_insert(ec, kv, read_index);
             st[1]++;                                                             // :387
         }
@@ -921,6 +923,44 @@ F2Q_HD void anchor_step(const uint32_t (&P)[NW], int j, uint32_t (&cnt)[KB > 0 ?
     }
 }
 
+// two positions of the same plane at once: the low counter bit takes both through one full adder (sum and carry are
+// single three-input instructions on gfx950), the carry ripples as before -- 5 instructions per word for two
+// positions with one counter bit instead of 6, 9 instead of 16 with three
+template <int NW, int KB>
+F2Q_HD void anchor_step2(const uint32_t (&P)[NW], int j1, int j2, uint32_t (&cnt)[KB > 0 ? KB : 1][NW], uint32_t (&ovf)[NW])
+{
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t up = w + 1 < NW ? P[w + 1] : ~0u;
+        const uint32_t x1 = funnel_shr(up, P[w], j1), x2 = funnel_shr(up, P[w], j2);
+        if (KB == 0) ovf[w] |= x1 | x2;
+        else {
+            const uint32_t c0 = cnt[0][w];
+#if defined(__HIP_DEVICE_COMPILE__)
+            uint32_t x = __builtin_amdgcn_bitop3_b32(c0, x1, x2, 0xE8);          // majority = the carry
+            cnt[0][w] = __builtin_amdgcn_bitop3_b32(c0, x1, x2, 0x96);           // parity = the sum
+#else
+            uint32_t x = (c0 & x1) | (c0 & x2) | (x1 & x2);
+            cnt[0][w] = c0 ^ x1 ^ x2;
+#endif
+#pragma unroll
+            for (int b = 1; b < KB; b++) { uint32_t c = cnt[b][w] & x; cnt[b][w] ^= x; x = c; }
+            ovf[w] |= x;
+        }
+    }
+}
+template <int NW, int KB>
+F2Q_HD void anchor_steps(const uint32_t (&P)[NW], uint32_t m, uint32_t (&cnt)[KB > 0 ? KB : 1][NW], uint32_t (&ovf)[NW])
+{
+    // pairs in a branch-free loop body, the odd position after it (a two-way body costs a register shuffle per pass)
+    while (m & (m - 1u)) {
+        const int j1 = ctz32(m); m &= m - 1u;
+        const int j2 = ctz32(m); m &= m - 1u;
+        anchor_step2<NW, KB>(P, j1, j2, cnt, ovf);
+    }
+    if (m) anchor_step<NW, KB>(P, ctz32(m), cnt, ovf);
+}
+
 // bit-sliced "count <= k" over the counters of one anchor
 template <int NW, int KB>
 F2Q_HD void anchor_compare(const uint32_t (&cnt)[KB > 0 ? KB : 1][NW], const uint32_t (&ovf)[NW], int k, uint32_t (&hit)[NW])
@@ -961,10 +1001,8 @@ F2Q_HD void anchor_hits2(const RunDev &run, const uint32_t (&LO)[NW], const uint
         uint32_t P[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++) P[w] = (LO[w] ^ la) | (HI[w] ^ ha) | FLG[w];   // 1 = base is not symbol c (flagged: never)
-        if (run.has_up)
-            for (uint32_t m = run.up_pos[c]; m; m &= m - 1u) anchor_step<NW, KBU>(P, ctz32(m), cu, ou);
-        if (run.has_down)
-            for (uint32_t m = run.down_pos[c]; m; m &= m - 1u) anchor_step<NW, KBD>(P, ctz32(m), cd, od);
+        if (run.has_up) anchor_steps<NW, KBU>(P, run.up_pos[c], cu, ou);
+        if (run.has_down) anchor_steps<NW, KBD>(P, run.down_pos[c], cd, od);
     }
     anchor_compare<NW, KBU>(cu, ou, run.msu, hu);
     anchor_compare<NW, KBD>(cd, od, run.msd, hd);
@@ -1009,21 +1047,29 @@ F2Q_HD uint32_t plane_extract(const uint32_t (&P)[NW], int start, int L)
 }
 
 // Phred fail bits of 32 bases from their 8 quality words (bytes < 128); add_hi == 0: rule off
+// Planar tiles keep the quality bytes of each 32-base group transposed: byte b of the group's word w holds base
+// 32g + 8b + w (planar_qpos).  The SWAR test leaves its verdict in bit 7 of every byte, so word w shifted right by
+// 7 - w drops its four verdicts on bits w, 8 + w, 16 + w, 24 + w: eight shift-ORs build the 32-base fail word, no
+// bit gather (the multiply it took before is a quarter-rate instruction).
+F2Q_HD uint32_t planar_qpos(uint32_t w, uint32_t b) { return 32u * (w >> 3) + 8u * b + (w & 7u); }
+F2Q_HD uint32_t planar_qword(uint32_t pos) { return 8u * (pos >> 5) + (pos & 7u); }
+F2Q_HD uint32_t planar_qbyte(uint32_t pos) { return (pos & 31u) >> 3; }
+// STRIP = false: the caller knows that no byte carries a flag (bit 7), e.g. no read of the wave is flagged
+template <bool STRIP = true>
 F2Q_HD uint32_t fail_word8(const uint32_t (&q)[8], uint32_t add_hi)
 {
     if (!add_hi) return 0u;
     uint32_t f = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        f |= ((((qfail4(q[i] & 0x7F7F7F7Fu, 0x5F5F5F5Fu, add_hi, 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);   // bit 7 = flag, not quality
+        f |= qfail4(STRIP ? (q[i] & 0x7F7F7F7Fu) : q[i], 0x5F5F5F5Fu, add_hi, 0x80808080u) >> (7 - i);   // bit 7 = flag, not quality
     return f;
 }
-// non-ACGT flag bits (bit 7 of the quality bytes) of 32 bases from their 8 quality words
 F2Q_HD uint32_t flag_word8(const uint32_t (&q)[8])
 {
     uint32_t f = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) f |= (((((q[i] & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);
+    for (int i = 0; i < 8; i++) f |= (q[i] & 0x80808080u) >> (7 - i);
     return f;
 }
 F2Q_HD uint32_t phred_add_hi(int thr) { return thr >= 33 ? (uint32_t)(127 - thr) * 0x01010101u : 0u; }
@@ -1171,10 +1217,12 @@ F2Q_HD void pack_read(const PackPlan &pl, const RecT<P> &r, uint32_t planar_nw, 
             sink.base(w, v);
         }
     }
-    for (uint32_t w = 0; w * 4 < l; w++) {
+    const uint32_t n_qwords = planar_nw ? 8u * ((l + 31u) / 32u) : (l + 3u) / 4u;
+    for (uint32_t w = 0; w < n_qwords; w++) {
         uint32_t v = 0;
-        for (uint32_t j = 0; j < 4 && w * 4 + j < l; j++) {
-            const uint32_t pos = w * 4 + j;
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t pos = planar_nw ? planar_qpos(w, j) : w * 4 + j;     // planar tiles: transposed groups (fail_word8)
+            if (pos >= l) continue;
             uint32_t q = r.qual[pos];
             q = (q & 0x80u) ? 0u : q;                               // keep every stored byte 7-bit (SWAR)
             const uint8_t sc = planar_nw ? (uint8_t)r.seq[pos] : up8(r.seq[pos]);

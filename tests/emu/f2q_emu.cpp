@@ -135,7 +135,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                 uint8_t sq[F2Q_ANCHOR_MAXLEN], ql[F2Q_ANCHOR_MAXLEN];
                 for (int i = 0; i < r; i++) {
                     sq[i] = (uint8_t)"ACGT"[((LO[i >> 5] >> (i & 31)) & 1u) | (((HI[i >> 5] >> (i & 31)) & 1u) << 1)];
-                    ql[i] = (uint8_t)((Q[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                    ql[i] = (uint8_t)((Q[planar_qword((uint32_t)i)] >> (8 * planar_qbyte((uint32_t)i))) & 0xFFu);
                     if (ql[i] & 0x80u) { sq[i] = (uint8_t)'N'; ql[i] &= 0x7Fu; }
                 }
                 general_read<const uint8_t *>(e->run, e->lib, e->ec, acc, sq, r, ql, r, gi, acc.stats);
