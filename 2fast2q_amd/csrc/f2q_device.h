@@ -1035,14 +1035,18 @@ F2Q_HD bool any_in_range(const uint32_t (&F)[NW], int a, int b)
 template <int NW>
 F2Q_HD uint32_t plane_extract(const uint32_t (&P)[NW], int start, int L)
 {
-    const int wi = start >> 5;
-    uint32_t lo = 0, hi = 0;
+    // every adjacent word pair is funnel-shifted by the in-word offset (the shift amount is per lane), then the word
+    // index picks one of them through a 3-level select tree on its bits: NW + 4 instructions + 3 compares instead of
+    // a compare-and-select pair per word for each of the two source words.  Needs 0 <= start < 256.
+    static_assert(NW <= 8, "plane_extract: at most 8 words");
+    const uint32_t sh = (uint32_t)start & 31u, wi = (uint32_t)start >> 5;
+    uint32_t V[8];
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-        if (w == wi) lo = P[w];
-        if (w == wi + 1) hi = P[w];
-    }
-    const uint32_t v = funnel_shr(hi, lo, start & 31);
+    for (int w = 0; w < 8; w++) V[w] = w < NW ? funnel_shr(w + 1 < NW ? P[w + 1] : 0u, P[w], sh) : 0u;
+    const bool b0 = wi & 1u, b1 = wi & 2u, b2 = wi & 4u;
+    const uint32_t t0 = b0 ? V[1] : V[0], t1 = b0 ? V[3] : V[2], t2 = b0 ? V[5] : V[4], t3 = b0 ? V[7] : V[6];
+    const uint32_t u0 = b1 ? t1 : t0, u1 = b1 ? t3 : t2;
+    const uint32_t v = b2 ? u1 : u0;
     return L >= 32 ? v : (v & ((1u << L) - 1u));
 }
 

@@ -65,6 +65,27 @@ def test_truncated_gzip_partial_counts(tmp_path, capsys):
     assert "incomplete or corrupted gzip" in capsys.readouterr().out
 
 
+def test_empty_and_tiny_files(tmp_path):
+    """files with nothing / less than one record / one record without a final newline: the reader thread, the carry
+    and the end-of-file piece of f2q_count_file"""
+    guides = synth.make_library(20, 20, 3)
+    one = b"@r\n" + guides[3].encode() + b"\n+\n" + b"I" * 20
+    cases = {"empty.fastq": (b"", 0), "three_lines.fastq": (b"@r\nACGT\n+\n", 0), "one.fastq": (one, 1),
+             "one_and_a_bit.fastq": (one + b"\n@x\nAC", 1)}
+    with pkg().Counter(features=guides, miss=0) as c:
+        for name, (data, n) in cases.items():
+            for kind in ("plain", "gzip", "bgzf"):
+                path = tmp_path / (name if kind == "plain" else name + ".gz")
+                path.write_bytes({"plain": data, "gzip": gzip.compress(data), "bgzf": bgzf_bytes(data)}[kind])
+                c.reset()
+                t, trunc = c.count_file(str(path))
+                counts, stats = c.read_counts()
+                assert not trunc and stats[0] == n and sum(counts) == n and (n == 0 or counts[3] == 1), (name, kind)
+    with pytest.raises(pkg().binding.F2QError):
+        with pkg().Counter(features=guides) as c:
+            c.count_file(str(tmp_path / "does_not_exist.fastq"))
+
+
 def test_cli_test_mode_end_to_end(tmp_path, monkeypatch):
     """`2fast2q -c -t` (reference tests/test_cli.py): exit 0, one output folder, exactly 6 files; and -- what
     upstream leaves commented out -- compiled.csv equals an independent count of the same input."""
