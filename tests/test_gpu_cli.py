@@ -208,6 +208,8 @@ def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk
     fq = synth.make_fastq(synth.Spec(seed=80, n_reads=9000, read_len=151), guides)
     fq = fq.replace(b"\n", b"\r\n", 3000)                      # some CRLF line ends
     fq += b"@long\n" + b"ACGT" * 3000 + b"\n+\n" + b"I" * 12000 + b"\n"      # a 12 kb read: longer than the smallest chunk
+    fq += synth.make_fastq(synth.Spec(seed=82, n_reads=300, read_len=75), guides)
+    fq += b"@huge\n" + guides[7].encode() + b"ACGT" * 20000 + b"\n+\n" + b"I" * 80020 + b"\n"   # 80 kb: longer than the carry head room
     fq += synth.make_fastq(synth.Spec(seed=81, n_reads=500, read_len=40), guides)[:-1]   # no final newline
     path = tmp_path / ("f.fastq" if gz == "plain" else "f.fastq.gz")
     path.write_bytes({"plain": fq, "gzip": gzip.compress(fq, 1), "bgzf": bgzf_bytes(fq, block=20000)}[gz])
