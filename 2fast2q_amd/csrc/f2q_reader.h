@@ -5,10 +5,11 @@
 //   BGZF   blocked gzip (bgzip, BCL Convert, samtools): every member carries its compressed size in a 'BC'
 //          extra field, so the members of one batch are inflated by a pool of workers, each straight into its
 //          final place in the caller's buffer; CRC32 and ISIZE of every member are checked like gzip does
-//   GZIP   anything else that starts with 1f 8b: zlib's gzread (one sequential inflate; multi-member aware)
+//   GZIP   anything else that starts with 1f 8b: one sequential raw inflate (zlib) on the reader thread; the CRC32 of
+//          the text, which gzread would compute on the same thread, is taken per piece by the worker pool
+//          (slices + crc32_combine), header/trailer/multi-member handling is done here
 //
-// A BGZF file that turns into ordinary gzip half way (concatenated files) is continued with gzread from the
-// uncompressed offset reached.  A damaged or cut-off stream delivers the text before the damage and then
+// A BGZF file that turns into ordinary gzip half way (concatenated files) is continued as GZIP from that member.  A damaged or cut-off stream delivers the text before the damage and then
 // reports `truncated()` — the reference returns None for such a file (:580-582), the harness does the same.
 #pragma once
 #include <fcntl.h>
@@ -28,7 +29,10 @@ struct TextSource {
     enum Kind { NONE, PLAIN, GZIP, BGZF };
     Kind kind = NONE;
     int fd = -1;
-    gzFile gz = nullptr;
+    // GZIP state: buffered compressed input, one raw inflate stream per member
+    std::vector<uint8_t> zin; size_t zpos = 0, zlen = 0; bool zeof = false;
+    z_stream zs; bool zs_live = false, in_member = false;
+    uint32_t m_crc = 0; uint64_t m_len = 0;      // CRC32 / length of the current member's text so far
     std::string path;
     bool regular = false, bad = false, done = false;
     uint64_t file_size = 0, file_pos = 0;       // PLAIN / BGZF: compressed bytes taken from the file
@@ -82,7 +86,8 @@ struct TextSource {
 
     void close()
     {
-        if (gz) { gzclose(gz); gz = nullptr; }
+        if (zs_live) { inflateEnd(&zs); zs_live = false; }
+        in_member = false; zpos = zlen = 0; zeof = false; m_crc = 0; m_len = 0;
         if (fd >= 0) { ::close(fd); fd = -1; }
         kind = NONE; bad = done = c_eof = false; file_pos = out_total = 0; cbuf.clear(); cpos = 0; spill.clear(); spill_pos = 0;
     }
@@ -101,14 +106,12 @@ struct TextSource {
     }
 
 private:
-    int open_gzip(uint64_t skip, std::string &err)
+    // continue (or start) as ordinary gzip from compressed offset `from`
+    int open_gzip(uint64_t from, std::string &err)
     {
-        if (fd >= 0) { ::close(fd); fd = -1; }
-        gz = gzopen(path.c_str(), "rb");
-        if (!gz) { err = std::string("cannot open ") + path; return -1; }
-        gzbuffer(gz, 1 << 20);
-        kind = GZIP;
-        if (skip && gzseek(gz, (z_off_t)skip, SEEK_SET) < 0) bad = true;
+        (void)err;
+        kind = GZIP; file_pos = from;
+        zin.resize((size_t)4 << 20); zpos = zlen = 0; zeof = false; in_member = false;
         return 0;
     }
 
@@ -152,20 +155,95 @@ private:
     }
 
     // ---- ordinary gzip -----------------------------------------------------------------------------
+    bool z_fill()
+    {
+        if (zeof) return false;
+        zpos = zlen = 0;
+        while (zlen < zin.size()) {
+            ssize_t r = regular ? pread(fd, zin.data() + zlen, zin.size() - zlen, (off_t)file_pos) : ::read(fd, zin.data() + zlen, zin.size() - zlen);
+            if (r <= 0) { zeof = true; break; }
+            zlen += (size_t)r; file_pos += (uint64_t)r;
+            if (!regular) break;                          // pipes: take what is there
+        }
+        return zlen > 0;
+    }
+    int z_get() { if (zpos == zlen && !z_fill()) return -1; return zin[zpos++]; }
+    bool z_skip(size_t n) { while (n--) if (z_get() < 0) return false; return true; }
+    bool z_skip_zstring() { for (;;) { int c = z_get(); if (c < 0) return false; if (c == 0) return true; } }
+
+    // 1 = a member header was read, 0 = clean end of the data (or trailing garbage, ignored like gzread does), -1 = cut off
+    int z_member_header()
+    {
+        int c0 = z_get();
+        while (c0 == 0) c0 = z_get();                     // zero padding between / after members
+        if (c0 < 0) return 0;
+        const int c1 = z_get();
+        if (c0 != 0x1f || c1 != 0x8b) return 0;
+        const int cm = z_get(), flg = z_get();
+        if (cm != 8 || flg < 0 || (flg & 0xE0)) return -1;
+        if (!z_skip(6)) return -1;                        // mtime, xfl, os
+        if (flg & 4) { const int a = z_get(), b = z_get(); if (b < 0 || !z_skip((size_t)a | ((size_t)b << 8))) return -1; }
+        if ((flg & 8) && !z_skip_zstring()) return -1;
+        if ((flg & 16) && !z_skip_zstring()) return -1;
+        if ((flg & 2) && !z_skip(2)) return -1;
+        return 1;
+    }
+
+    static uint32_t crc_parallel(const uint8_t *p, size_t n, int threads)
+    {
+        const size_t slice_min = (size_t)2 << 20;
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / slice_min));
+        if (T == 1) return (uint32_t)crc32_z(crc32(0L, Z_NULL, 0), p, n);
+        std::vector<uint32_t> part((size_t)T);
+        auto work = [&](int t) {
+            const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T;
+            part[(size_t)t] = (uint32_t)crc32_z(crc32(0L, Z_NULL, 0), p + a, b - a);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        uLong c = part[0];
+        for (int t = 1; t < T; t++) c = crc32_combine(c, part[(size_t)t], (z_off_t)(n * (size_t)(t + 1) / (size_t)T - n * (size_t)t / (size_t)T));
+        return (uint32_t)c;
+    }
+    void z_account(const uint8_t *p, size_t n)
+    {
+        if (!n) return;
+        const uint32_t c = crc_parallel(p, n, n_threads);
+        m_crc = m_len ? (uint32_t)crc32_combine(m_crc, c, (z_off_t)n) : c;
+        m_len += n;
+    }
+
     size_t read_gzip(uint8_t *dst, size_t cap)
     {
-        if (bad) return 0;
-        size_t n = 0;
-        while (n < cap) {
-            int r = gzread(gz, dst + n, (unsigned)std::min<size_t>(cap - n, 1u << 30));
-            if (r < 0) { bad = true; break; }
-            if (r == 0) {
-                int zerr = 0; (void)gzerror(gz, &zerr);
-                if (zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR) bad = true;
-                break;
+        size_t n = 0, seg = 0;                            // seg: start of the current member's text inside dst
+        while (n < cap && !bad) {
+            if (!in_member) {
+                const int h = z_member_header();
+                if (h < 0) { bad = true; break; }
+                if (h == 0) break;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) { bad = true; break; }
+                zs_live = true; in_member = true; m_crc = 0; m_len = 0; seg = n;
             }
-            n += (size_t)r;
+            if (zpos == zlen && !z_fill()) { bad = true; break; }         // member cut off
+            zs.next_in = zin.data() + zpos; zs.avail_in = (uInt)std::min<size_t>(zlen - zpos, 1u << 30);
+            zs.next_out = dst + n; zs.avail_out = (uInt)std::min<size_t>(cap - n, 1u << 30);
+            const uInt in0 = zs.avail_in, out0 = zs.avail_out;
+            const int r = inflate(&zs, Z_NO_FLUSH);
+            zpos += in0 - zs.avail_in; n += out0 - zs.avail_out;
+            if (r == Z_STREAM_END) {
+                inflateEnd(&zs); zs_live = false; in_member = false;
+                z_account(dst + seg, n - seg);
+                uint32_t t[2] = {0, 0};
+                bool ok = true;
+                for (int k = 0; k < 8 && ok; k++) { const int c = z_get(); if (c < 0) ok = false; else t[k >> 2] |= (uint32_t)c << (8 * (k & 3)); }
+                if (!ok || t[0] != m_crc || t[1] != (uint32_t)m_len) { bad = true; break; }
+            } else if (r != Z_OK && r != Z_BUF_ERROR) { bad = true; break; }
+            else if (r == Z_BUF_ERROR && zs.avail_in != 0 && zs.avail_out != 0) { bad = true; break; }
         }
+        if (in_member) z_account(dst + seg, n - seg);     // the member goes on in the next piece
         return n;
     }
 
@@ -296,9 +374,11 @@ private:
             if (fb < ms.size()) { bad = true; foreign = false; n = ms[fb].o_off; cpos = ms[fb].c_off; }
             else { n = o_off; cpos = scan; }
         }
-        if (n == 0 && foreign && !bad) {                      // the rest is ordinary gzip: let zlib walk it
+        if (n == 0 && foreign && !bad) {                      // the rest is ordinary gzip: continue from that member
             std::string err;
-            if (open_gzip(out_total, err) != 0) { bad = true; return 0; }
+            const uint64_t at = file_pos - (uint64_t)(cbuf.size() - scan);
+            cbuf.clear(); cpos = 0;
+            if (open_gzip(at, err) != 0) { bad = true; return 0; }
             return read_gzip(dst, cap);
         }
         // empty members (the BGZF end marker) produce nothing: keep going until text or the end

@@ -122,3 +122,50 @@ def test_gzip_cut_off(tmp_path, payload):
 def test_gz_content_sniffed_not_named(tmp_path, payload):
     z = tmp_path / "noext"; z.write_bytes(gzip.compress(payload))
     assert read_file(z)[0] == payload
+
+
+def gz_member(data, name=None, comment=None, extra=None, hcrc=False, level=6):
+    """one gzip member with optional header fields (RFC 1952)"""
+    flg = (4 if extra is not None else 0) | (8 if name is not None else 0) | (16 if comment is not None else 0) | (2 if hcrc else 0)
+    head = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\x00\x03"
+    if extra is not None: head += len(extra).to_bytes(2, "little") + extra
+    if name is not None: head += name + b"\0"
+    if comment is not None: head += comment + b"\0"
+    if hcrc: head += (zlib.crc32(head) & 0xFFFF).to_bytes(2, "little")
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = co.compress(data) + co.flush()
+    return head + body + (zlib.crc32(data) & 0xFFFFFFFF).to_bytes(4, "little") + (len(data) & 0xFFFFFFFF).to_bytes(4, "little")
+
+
+def test_gzip_header_fields_padding_and_garbage(tmp_path, payload):
+    a, b, c = payload[:70_000], payload[70_000:70_001], payload[70_001:]
+    raw = gz_member(a, name=b"x.fastq", comment=b"hello", extra=b"ABCDEFG", hcrc=True) + gz_member(b, level=0) + b"\0" * 37 + gz_member(c, name=b"y")
+    z = tmp_path / "h.gz"; z.write_bytes(raw)
+    assert gzip.open(z).read() == payload
+    for piece in (4096, 70_000, 1 << 20):
+        assert read_file(z, piece, 3) == (payload, False, "gzip")
+    z2 = tmp_path / "g.gz"; z2.write_bytes(raw + b"\0" * 5 + b"garbage that is not gzip")
+    assert read_file(z2, 1 << 16, 2) == (payload, False, "gzip")            # ignored, like zlib's gzread
+    z3 = tmp_path / "e.gz"; z3.write_bytes(gz_member(b"") + gz_member(payload[:10]) + gz_member(b""))
+    assert read_file(z3) == (payload[:10], False, "gzip")
+
+
+def test_gzip_wrong_crc_or_size(tmp_path, payload):
+    good = gz_member(payload[:50_000])
+    for k in (-8, -4):
+        raw = bytearray(good); raw[k] ^= 1
+        z = tmp_path / f"bad{-k}.gz"; z.write_bytes(bytes(raw) + gz_member(payload[50_000:60_000]))
+        got, tr, kind = read_file(z, 1 << 16, 2)
+        assert tr and got == payload[:50_000]                                  # the text is delivered, then the damage reported
+
+
+def test_gzip_large_parallel_crc(tmp_path):
+    data = text(90_000, seed=5)                                                # ~16 MB: several pieces, sliced CRC
+    assert len(data) > (12 << 20)
+    z = tmp_path / "big.gz"; z.write_bytes(gz_member(data[: 9 << 20], level=1) + gz_member(data[9 << 20:], level=1))
+    for piece, th in ((6 << 20, 4), (32 << 20, 8), (1 << 20, 1)):
+        got, tr, kind = read_file(z, piece, th, out_cap=20 << 20)
+        assert (got == data, tr, kind) == (True, False, "gzip")
+    # the member boundary exactly on a piece boundary
+    got, tr, kind = read_file(z, 3 << 20, 4, out_cap=20 << 20)
+    assert got == data and not tr
