@@ -15,6 +15,7 @@
 #include <fcntl.h>
 #include <stdint.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -25,6 +26,8 @@
 #include <thread>
 #include <vector>
 
+#include "f2q_inflate.h"
+
 struct TextSource {
     enum Kind { NONE, PLAIN, GZIP, BGZF };
     Kind kind = NONE;
@@ -33,6 +36,10 @@ struct TextSource {
     std::vector<uint8_t> zin; size_t zpos = 0, zlen = 0; bool zeof = false;
     z_stream zs; bool zs_live = false, in_member = false;
     uint32_t m_crc = 0; uint64_t m_len = 0;      // CRC32 / length of the current member's text so far
+    // regular files: the compressed bytes are memory-mapped and decoded by f2qz::Inflater (F2Q_ZLIB=1: zlib instead)
+    const uint8_t *zmap = nullptr; size_t zmap_len = 0, zoff = 0;
+    f2qz::Inflater *infl = nullptr;
+    bool use_zlib = false;
     std::string path;
     bool regular = false, bad = false, done = false;
     uint64_t file_size = 0, file_pos = 0;       // PLAIN / BGZF: compressed bytes taken from the file
@@ -63,6 +70,7 @@ struct TextSource {
     {
         close();
         path = p; n_threads = default_threads();
+        { const char *z = getenv("F2Q_ZLIB"); use_zlib = z && z[0] == '1'; }
         fd = ::open(p, O_RDONLY);
         if (fd < 0) { err = std::string("cannot open ") + p; return -1; }
         struct stat st;
@@ -87,6 +95,8 @@ struct TextSource {
     void close()
     {
         if (zs_live) { inflateEnd(&zs); zs_live = false; }
+        if (zmap) { munmap(const_cast<uint8_t *>(zmap), zmap_len); zmap = nullptr; zmap_len = 0; }
+        delete infl; infl = nullptr; zoff = 0;
         in_member = false; zpos = zlen = 0; zeof = false; m_crc = 0; m_len = 0;
         if (fd >= 0) { ::close(fd); fd = -1; }
         kind = NONE; bad = done = c_eof = false; file_pos = out_total = 0; cbuf.clear(); cpos = 0; spill.clear(); spill_pos = 0;
@@ -98,7 +108,7 @@ struct TextSource {
         if (done || cap == 0) return 0;
         size_t n = 0;
         if (kind == PLAIN) n = read_plain(dst, cap);
-        else if (kind == GZIP) n = read_gzip(dst, cap);
+        else if (kind == GZIP) n = zmap ? read_gzip_mm(dst, cap) : read_gzip(dst, cap);
         else if (kind == BGZF) n = read_bgzf(dst, cap);
         if (n == 0) done = true;
         out_total += n;
@@ -110,8 +120,17 @@ private:
     int open_gzip(uint64_t from, std::string &err)
     {
         (void)err;
-        kind = GZIP; file_pos = from;
-        zin.resize((size_t)4 << 20); zpos = zlen = 0; zeof = false; in_member = false;
+        kind = GZIP; file_pos = from; in_member = false;
+        if (regular && !use_zlib && file_size > 0) {
+            void *m = mmap(nullptr, (size_t)file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)file_size, MADV_SEQUENTIAL);
+                zmap = (const uint8_t *)m; zmap_len = (size_t)file_size; zoff = (size_t)from;
+                infl = new f2qz::Inflater();
+                return 0;
+            }
+        }
+        zin.resize((size_t)4 << 20); zpos = zlen = 0; zeof = false;
         return 0;
     }
 
@@ -247,6 +266,56 @@ private:
         return n;
     }
 
+    // gzip member header at zmap[zoff..): same verdicts as z_member_header
+    int mm_member_header()
+    {
+        while (zoff < zmap_len && zmap[zoff] == 0) zoff++;
+        if (zoff >= zmap_len) return 0;
+        if (zmap_len - zoff < 2 || zmap[zoff] != 0x1f || zmap[zoff + 1] != 0x8b) return 0;
+        size_t p = zoff + 2;
+        auto get = [&]() -> int { return p < zmap_len ? zmap[p++] : -1; };
+        const int cm = get(), flg = get();
+        if (cm != 8 || flg < 0 || (flg & 0xE0)) return -1;
+        for (int k = 0; k < 6; k++) if (get() < 0) return -1;
+        if (flg & 4) { const int a = get(), b = get(); if (b < 0) return -1; const size_t n = (size_t)a | ((size_t)b << 8); if (zmap_len - p < n) return -1; p += n; }
+        if (flg & 8) { for (;;) { const int c = get(); if (c < 0) return -1; if (c == 0) break; } }
+        if (flg & 16) { for (;;) { const int c = get(); if (c < 0) return -1; if (c == 0) break; } }
+        if (flg & 2) { if (get() < 0 || get() < 0) return -1; }
+        zoff = p;
+        return 1;
+    }
+
+    size_t read_gzip_mm(uint8_t *dst, size_t cap)
+    {
+        size_t n = 0, seg = 0;
+        while (n < cap && !bad) {
+            if (!in_member) {
+                const int h = mm_member_header();
+                if (h < 0) { bad = true; break; }
+                if (h == 0) break;
+                infl->reset(zmap + zoff, zmap_len - zoff);
+                in_member = true; m_crc = 0; m_len = 0; seg = n;
+            }
+            size_t got = 0;
+            const f2qz::Inflater::Status r = infl->run(dst + n, dst + cap, &got);
+            n += got;
+            if (r == f2qz::Inflater::ERR) { bad = true; break; }
+            if (r == f2qz::Inflater::DONE) {
+                in_member = false;
+                z_account(dst + seg, n - seg);
+                zoff = (size_t)(infl->input_pos() - zmap);
+                if (zmap_len - zoff < 8) { bad = true; break; }
+                const uint8_t *t = zmap + zoff;
+                const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+                const uint32_t isz = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+                zoff += 8;
+                if (crc != m_crc || isz != (uint32_t)m_len) { bad = true; break; }
+            }
+        }
+        if (in_member) z_account(dst + seg, n - seg);
+        return n;
+    }
+
     // ---- BGZF ---------------------------------------------------------------------------------------
     // gzip member header with a 'BC' extra subfield: *bsize = whole member size in bytes
     static bool bgzf_header(const uint8_t *h, size_t avail, uint32_t &bsize)
@@ -280,22 +349,32 @@ private:
         return n > 0;
     }
 
-    static bool inflate_member(const uint8_t *src, const Member &m, uint8_t *out)
+    static bool inflate_member(const uint8_t *src, const Member &m, uint8_t *out, bool with_zlib)
     {
         if (m.c_len < m.hdr + 8) return false;
-        z_stream zs; memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) return false;
-        zs.next_in = const_cast<Bytef *>(src + m.c_off + m.hdr); zs.avail_in = m.c_len - m.hdr - 8;
-        zs.next_out = out; zs.avail_out = m.isize;
-        Bytef dummy[8];
-        if (m.isize == 0) { zs.next_out = dummy; zs.avail_out = sizeof dummy; }
-        const int r = inflate(&zs, Z_FINISH);
-        const bool ok = (r == Z_STREAM_END) && zs.total_out == m.isize && zs.avail_in == 0;
-        inflateEnd(&zs);
-        if (!ok) return false;
         const uint8_t *tail = src + m.c_off + m.c_len - 8;
         const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
-        return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, m.isize) == crc;
+        if (with_zlib) {
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            zs.next_in = const_cast<Bytef *>(src + m.c_off + m.hdr); zs.avail_in = m.c_len - m.hdr - 8;
+            zs.next_out = out; zs.avail_out = m.isize;
+            Bytef dummy[8];
+            if (m.isize == 0) { zs.next_out = dummy; zs.avail_out = sizeof dummy; }
+            const int r = inflate(&zs, Z_FINISH);
+            const bool ok = (r == Z_STREAM_END) && zs.total_out == m.isize && zs.avail_in == 0;
+            inflateEnd(&zs);
+            if (!ok) return false;
+        } else {
+            static thread_local f2qz::Inflater *inf = nullptr;        // 55 KB of tables: one per worker thread
+            if (!inf) inf = new f2qz::Inflater();
+            inf->reset(src + m.c_off + m.hdr, m.c_len - m.hdr - 8);
+            size_t got = 0;
+            uint8_t none[1];
+            const f2qz::Inflater::Status r = inf->run(m.isize ? out : none, (m.isize ? out : none) + m.isize, &got);
+            if (r != f2qz::Inflater::DONE || got != m.isize || inf->input_pos() != tail) return false;
+        }
+        return (uint32_t)crc32_z(crc32(0L, Z_NULL, 0), out, m.isize) == crc;
     }
 
     size_t read_bgzf(uint8_t *dst, size_t cap)
@@ -341,7 +420,7 @@ private:
                 // one member larger than the room offered: inflate aside and hand out in pieces
                 Member m{scan, bsize, 12 + xlen, isize, 0};
                 spill.assign(isize, 0); spill_pos = 0;
-                if (!inflate_member(cbuf.data(), m, spill.data())) { spill.clear(); bad = true; return 0; }
+                if (!inflate_member(cbuf.data(), m, spill.data(), use_zlib)) { spill.clear(); bad = true; return 0; }
                 cpos = scan + bsize;
                 return read_bgzf(dst, cap);
             }
@@ -357,7 +436,7 @@ private:
                     const size_t i = next.fetch_add(16);
                     if (i >= ms.size()) return;
                     for (size_t j = i; j < std::min(i + 16, ms.size()); j++)
-                        if (!inflate_member(cbuf.data(), ms[j], dst + ms[j].o_off)) {
+                        if (!inflate_member(cbuf.data(), ms[j], dst + ms[j].o_off, use_zlib)) {
                             size_t cur = first_bad.load();
                             while (j < cur && !first_bad.compare_exchange_weak(cur, j)) {}
                         }
@@ -379,7 +458,7 @@ private:
             const uint64_t at = file_pos - (uint64_t)(cbuf.size() - scan);
             cbuf.clear(); cpos = 0;
             if (open_gzip(at, err) != 0) { bad = true; return 0; }
-            return read_gzip(dst, cap);
+            return zmap ? read_gzip_mm(dst, cap) : read_gzip(dst, cap);
         }
         // empty members (the BGZF end marker) produce nothing: keep going until text or the end
         if (n == 0 && !bad && !ms.empty()) return read_bgzf(dst, cap);

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("2fast2q_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 guides = pkg.binding.synth_library(0xF2A5 + 3, 10000, 20)
-d = tempfile.mkdtemp()
+d = os.environ.get("KEEP_DIR") or tempfile.mkdtemp()
 with pkg.Counter(features=guides, miss=1) as c:
     fq = bytes(c.synth_fastq(seed=1, n_reads=n, read_len=150))
     p = os.path.join(d, "x.fastq"); open(p, "wb").write(fq)
