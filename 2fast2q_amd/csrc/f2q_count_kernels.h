@@ -167,16 +167,13 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 row = row < pb.wb ? row : pb.wb - 1u;       // reads shorter than the window: stay inside the tile
                 brow[r] = ld_u4<NT>(bp + (uint64_t)row * F2Q_TILE);
             }
-            if (NQ || g.add_hi) {                        // --ph <= 1: no quality row is needed at all
+            // the quality rows are fetched even when the Phred rule is off (--ph <= 1): bit 7 of their bytes flags the
+            // non-ACGT symbols, and sending every flagged read down the byte-exact path instead cost 2x with 0.5 % of them
 #pragma unroll
-                for (int r = 0; r < QR; r++) {
-                    uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0)));
-                    row = row < pb.wq ? row : pb.wq - 1u;
-                    qrow[r] = ld_u4<NT>(qp + (uint64_t)row * F2Q_TILE);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < QR; r++) qrow[r] = U4{0, 0, 0, 0};
+            for (int r = 0; r < QR; r++) {
+                uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0)));
+                row = row < pb.wq ? row : pb.wq - 1u;
+                qrow[r] = ld_u4<NT>(qp + (uint64_t)row * F2Q_TILE);
             }
             uint32_t len01 = 0, len23 = 0;
             if (pb.len) {
@@ -193,9 +190,8 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
-                const bool have_q = NQ || g.add_hi;            // the flag bits travel in the quality rows
                 if (l == F2Q_LEN_SKIP) res[j] = R_SKIP;
-                else if ((int)(l & 0x7FFFu) < need || g.L < 1 || ((l & F2Q_LEN_FLAG) && !have_q)) res[j] = R_SLOW;
+                else if ((int)(l & 0x7FFFu) < need || g.L < 1) res[j] = R_SLOW;
                 else if (bad[j]) res[j] = R_QFAIL;
                 else {
                     res[j] = R_NEAR; key[j] = fixed4_key(g, brow, j);

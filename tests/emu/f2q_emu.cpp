@@ -231,7 +231,6 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                 U4 b[F2Q_MAXBROWS], qr[F2Q_MAXQROWS]; uint32_t bad[4] = {0, 0, 0, 0};
                 const uint32_t *qp = pb.qual + ((uint64_t)t * pb.wq) * F2Q_TILE + 4 * lane;
                 const uint32_t *bp = pb.bases + ((uint64_t)t * pb.wb) * F2Q_TILE + 4 * lane;
-                const bool have_q = g.add_hi != 0;
                 for (int r = 0; r < F2Q_MAXBROWS; r++) {
                     uint32_t row = g.bw0 + (r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
                     row = row < pb.wb ? row : pb.wb - 1;
@@ -241,7 +240,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     uint32_t row = g.qw0 + (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
                     row = row < pb.wq ? row : pb.wq - 1;
                     const uint32_t *p = qp + (uint64_t)row * F2Q_TILE;
-                    qr[r] = have_q ? U4{p[0], p[1], p[2], p[3]} : U4{0, 0, 0, 0};
+                    qr[r] = U4{p[0], p[1], p[2], p[3]};          // also with the Phred rule off: the flag bits travel here
                 }
                 if (g.add_hi)
                     for (int r = 0; r < F2Q_MAXQROWS; r++)
@@ -250,7 +249,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
                     int res; uint32_t idx = 0;
                     if (l == F2Q_LEN_SKIP) res = R_SKIP;
-                    else if ((int)(l & 0x7FFFu) < need || g.L < 1 || ((l & F2Q_LEN_FLAG) && !have_q))
+                    else if ((int)(l & 0x7FFFu) < need || g.L < 1)
                         res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
                     else if (bad[j]) res = R_QFAIL;
                     else {
