@@ -127,6 +127,10 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     uint32_t q_head = 0, q_tail = 0;          // the ring belongs to this wave alone: head and tail live in (uniform) registers
     const FixedGeom g = fixed_geom(run);
     const int need = g.st + g.L;
+    // the tiles hold every row the window touches (false only when all reads of the block end before it does: the
+    // row clamp below would then re-read a row, so such blocks keep the byte-exact routine for their short reads)
+    const bool rows_ok = (uint32_t)(g.qw0 + g.nq) <= pb.wq && (uint32_t)(g.bw0 + g.nb) <= pb.wb &&
+                         g.L >= 1 && g.L <= F2Q_REG_MAXLEN && lib.grp[g.L].n == nf;      // and every feature is L long
     const bool do_near = run.miss > 0;
     const PackedPiece ex = lib.pk.exact;
     const uint32_t ib = lib.pk.ib, exm = (1u << ex.bits) - 1u;
@@ -191,7 +195,13 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
             for (int j = 0; j < 4; j++) {
                 uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
                 if (l == F2Q_LEN_SKIP) res[j] = R_SKIP;
-                else if ((int)(l & 0x7FFFu) < need || g.L < 1) res[j] = R_SLOW;
+                else if (g.L < 1) res[j] = R_SLOW;
+                // a read that ends inside the window gives a clipped, shorter key (:354).  With rows_ok every feature
+                // is L long, so the key can equal or approach none (:683), and its bytes past the end are stored as 0
+                // and never fail, so bad[] already is the Phred test of the clipped window (:355-357); otherwise the
+                // byte-exact routine decides.  (Written as one test per line on purpose: hipcc 7.2 turned the
+                // equivalent `L < 1 || (short && !rows_ok)` form into code that dropped reads — fuzz case 101.)
+                else if ((int)(l & 0x7FFFu) < need) res[j] = rows_ok ? (bad[j] ? R_QFAIL : R_NONALIGNED) : R_SLOW;
                 else if (bad[j]) res[j] = R_QFAIL;
                 else {
                     res[j] = R_NEAR; key[j] = fixed4_key(g, brow, j);

@@ -226,6 +226,8 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
         // the v2 kernel's per-lane sequence: 4 reads per lane from 16-byte row loads, packed tables
         const FixedGeom g = fixed_geom(e->run);
         const int need = g.st + g.L;
+        const bool rows_ok = (uint32_t)(g.qw0 + g.nq) <= pb.wq && (uint32_t)(g.bw0 + g.nb) <= pb.wb &&
+                             g.L >= 1 && g.L <= F2Q_REG_MAXLEN && e->lib.grp[g.L].n == e->lib.n_features;
         for (uint32_t t = 0; t < hp.n_tiles; t++)
             for (uint32_t lane = 0; lane < 64; lane++) {
                 U4 b[F2Q_MAXBROWS], qr[F2Q_MAXQROWS]; uint32_t bad[4] = {0, 0, 0, 0};
@@ -249,8 +251,9 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
                     int res; uint32_t idx = 0;
                     if (l == F2Q_LEN_SKIP) res = R_SKIP;
-                    else if ((int)(l & 0x7FFFu) < need || g.L < 1)
+                    else if (g.L < 1 || ((int)(l & 0x7FFFu) < need && !rows_ok))
                         res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
+                    else if ((int)(l & 0x7FFFu) < need) res = bad[j] ? R_QFAIL : R_NONALIGNED;   // clipped window, uniform library
                     else if (bad[j]) res = R_QFAIL;
                     else {
                         uint64_t key = fixed4_key(g, b, j);
