@@ -95,7 +95,7 @@ __device__ __forceinline__ U4 ld_u4(const uint32_t F2Q_GLOBAL *p)
     return U4{v.x, v.y, v.z, v.w};
 }
 
-__device__ __noinline__ int slow_read(const RunDev *run, const LibDev *lib, const PackedBlock *pb, uint32_t tile,
+__device__ __forceinline__ int slow_read(const RunDev *run, const LibDev *lib, const PackedBlock *pb, uint32_t tile,
                                       uint32_t slot, uint32_t *idx)
 {
     return fixed_lane(*run, *lib, *pb, tile, slot, *idx);
