@@ -39,6 +39,7 @@ struct TextSource {
     // regular files: the compressed bytes are memory-mapped and decoded by f2qz::Inflater (F2Q_ZLIB=1: zlib instead)
     const uint8_t *zmap = nullptr; size_t zmap_len = 0, zoff = 0;
     f2qz::Inflater *infl = nullptr;
+    std::vector<f2qz::Inflater *> worker_infl;   // BGZF: one decoder (55 KB of tables) per worker of the pool
     bool use_zlib = false;
     std::string path;
     bool regular = false, bad = false, done = false;
@@ -97,6 +98,8 @@ struct TextSource {
         if (zs_live) { inflateEnd(&zs); zs_live = false; }
         if (zmap) { munmap(const_cast<uint8_t *>(zmap), zmap_len); zmap = nullptr; zmap_len = 0; }
         delete infl; infl = nullptr; zoff = 0;
+        for (auto *w : worker_infl) delete w;
+        worker_infl.clear();
         in_member = false; zpos = zlen = 0; zeof = false; m_crc = 0; m_len = 0;
         if (fd >= 0) { ::close(fd); fd = -1; }
         kind = NONE; bad = done = c_eof = false; file_pos = out_total = 0; cbuf.clear(); cpos = 0; spill.clear(); spill_pos = 0;
@@ -349,12 +352,19 @@ private:
         return n > 0;
     }
 
-    static bool inflate_member(const uint8_t *src, const Member &m, uint8_t *out, bool with_zlib)
+    f2qz::Inflater *worker_decoder(int t)
+    {
+        if (use_zlib) return nullptr;
+        while ((int)worker_infl.size() <= t) worker_infl.push_back(new f2qz::Inflater());
+        return worker_infl[(size_t)t];
+    }
+
+    static bool inflate_member(const uint8_t *src, const Member &m, uint8_t *out, f2qz::Inflater *inf)
     {
         if (m.c_len < m.hdr + 8) return false;
         const uint8_t *tail = src + m.c_off + m.c_len - 8;
         const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
-        if (with_zlib) {
+        if (!inf) {                                               // F2Q_ZLIB=1
             z_stream zs; memset(&zs, 0, sizeof zs);
             if (inflateInit2(&zs, -15) != Z_OK) return false;
             zs.next_in = const_cast<Bytef *>(src + m.c_off + m.hdr); zs.avail_in = m.c_len - m.hdr - 8;
@@ -366,8 +376,6 @@ private:
             inflateEnd(&zs);
             if (!ok) return false;
         } else {
-            static thread_local f2qz::Inflater *inf = nullptr;        // 55 KB of tables: one per worker thread
-            if (!inf) inf = new f2qz::Inflater();
             inf->reset(src + m.c_off + m.hdr, m.c_len - m.hdr - 8);
             size_t got = 0;
             uint8_t none[1];
@@ -420,7 +428,7 @@ private:
                 // one member larger than the room offered: inflate aside and hand out in pieces
                 Member m{scan, bsize, 12 + xlen, isize, 0};
                 spill.assign(isize, 0); spill_pos = 0;
-                if (!inflate_member(cbuf.data(), m, spill.data(), use_zlib)) { spill.clear(); bad = true; return 0; }
+                if (!inflate_member(cbuf.data(), m, spill.data(), worker_decoder(0))) { spill.clear(); bad = true; return 0; }
                 cpos = scan + bsize;
                 return read_bgzf(dst, cap);
             }
@@ -431,22 +439,24 @@ private:
         if (!ms.empty()) {
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, ms.size() / 4));
             std::atomic<size_t> next{0}, first_bad{ms.size()};
-            auto work = [&]() {
+            for (int t = 0; t < T; t++) (void)worker_decoder(t);        // created here, not in the workers
+            auto work = [&](int t) {
+                f2qz::Inflater *inf = worker_decoder(t);
                 for (;;) {
                     const size_t i = next.fetch_add(16);
                     if (i >= ms.size()) return;
                     for (size_t j = i; j < std::min(i + 16, ms.size()); j++)
-                        if (!inflate_member(cbuf.data(), ms[j], dst + ms[j].o_off, use_zlib)) {
+                        if (!inflate_member(cbuf.data(), ms[j], dst + ms[j].o_off, inf)) {
                             size_t cur = first_bad.load();
                             while (j < cur && !first_bad.compare_exchange_weak(cur, j)) {}
                         }
                 }
             };
-            if (T == 1) work();
+            if (T == 1) work(0);
             else {
                 std::vector<std::thread> th;
-                for (int t = 1; t < T; t++) th.emplace_back(work);
-                work();
+                for (int t = 1; t < T; t++) th.emplace_back(work, t);
+                work(0);
                 for (auto &x : th) x.join();
             }
             const size_t fb = first_bad.load();
