@@ -16,6 +16,40 @@
 
 namespace f2qz {
 
+// CRC-32 of gzip (reflected 0xEDB88320), slicing-by-16: 16 table look-ups per 16 input bytes.  zlib 1.2.11's crc32
+// runs at ~0.7 GB/s per thread on the test box, which made the checksum a third of a BGZF worker's time.
+struct Crc32 {
+    uint32_t t[16][256];
+    Crc32()
+    {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            t[0][i] = c;
+        }
+        for (int s = 1; s < 16; s++)
+            for (uint32_t i = 0; i < 256; i++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFFu];
+    }
+    // crc = 0 for a new message; the value of the bytes so far to continue one (same convention as zlib)
+    uint32_t update(uint32_t crc, const uint8_t *p, size_t n) const
+    {
+        crc = ~crc;
+        while (n >= 16) {
+            uint64_t a, b;
+            memcpy(&a, p, 8); memcpy(&b, p + 8, 8);
+            a ^= crc;
+            crc = t[15][a & 0xFF] ^ t[14][(a >> 8) & 0xFF] ^ t[13][(a >> 16) & 0xFF] ^ t[12][(a >> 24) & 0xFF] ^
+                  t[11][(a >> 32) & 0xFF] ^ t[10][(a >> 40) & 0xFF] ^ t[9][(a >> 48) & 0xFF] ^ t[8][a >> 56] ^
+                  t[7][b & 0xFF] ^ t[6][(b >> 8) & 0xFF] ^ t[5][(b >> 16) & 0xFF] ^ t[4][(b >> 24) & 0xFF] ^
+                  t[3][(b >> 32) & 0xFF] ^ t[2][(b >> 40) & 0xFF] ^ t[1][(b >> 48) & 0xFF] ^ t[0][b >> 56];
+            p += 16; n -= 16;
+        }
+        while (n--) crc = t[0][(crc ^ *p++) & 0xFFu] ^ (crc >> 8);
+        return ~crc;
+    }
+    static const Crc32 &get() { static const Crc32 c; return c; }
+};
+
 struct Inflater {
     enum Status { OUT_FULL = 0, DONE = 1, ERR = 2 };
 

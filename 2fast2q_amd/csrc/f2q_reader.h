@@ -214,12 +214,13 @@ private:
     static uint32_t crc_parallel(const uint8_t *p, size_t n, int threads)
     {
         const size_t slice_min = (size_t)2 << 20;
+        (void)f2qz::Crc32::get();                          // tables built before any worker uses them
         const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / slice_min));
-        if (T == 1) return (uint32_t)crc32_z(crc32(0L, Z_NULL, 0), p, n);
+        if (T == 1) return f2qz::Crc32::get().update(0u, p, n);
         std::vector<uint32_t> part((size_t)T);
         auto work = [&](int t) {
             const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T;
-            part[(size_t)t] = (uint32_t)crc32_z(crc32(0L, Z_NULL, 0), p + a, b - a);
+            part[(size_t)t] = f2qz::Crc32::get().update(0u, p + a, b - a);
         };
         std::vector<std::thread> th;
         for (int t = 1; t < T; t++) th.emplace_back(work, t);
@@ -382,7 +383,7 @@ private:
             const f2qz::Inflater::Status r = inf->run(m.isize ? out : none, (m.isize ? out : none) + m.isize, &got);
             if (r != f2qz::Inflater::DONE || got != m.isize || inf->input_pos() != tail) return false;
         }
-        return (uint32_t)crc32_z(crc32(0L, Z_NULL, 0), out, m.isize) == crc;
+        return f2qz::Crc32::get().update(0u, out, m.isize) == crc;
     }
 
     size_t read_bgzf(uint8_t *dst, size_t cap)

@@ -346,6 +346,8 @@ size_t emu_synth_fastq(void *h, const f2q_synth *s, uint64_t lo, uint64_t hi, ui
     return o;
 }
 
+uint32_t emu_crc32(uint32_t crc, const uint8_t *p, size_t n) { return f2qz::Crc32::get().update(crc, p, n); }
+
 // the file reader of f2q_count_file (f2q_reader.h), piece size `cap`: returns the bytes decoded, -1 if out is too small
 long long emu_read_file(const char *path, size_t cap, int threads, uint8_t *out, size_t out_cap, int *truncated, int *kind)
 {

@@ -53,6 +53,8 @@ def lib():
                                  C.POINTER(C.c_uint64)]
         L.emu_synth_fastq.restype = C.c_size_t
         L.emu_synth_fastq.argtypes = [vp, C.POINTER(binding.Synth), C.c_uint64, C.c_uint64, C.c_char_p]
+        L.emu_crc32.restype = C.c_uint32
+        L.emu_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
         L.emu_read_file.restype = C.c_longlong
         L.emu_read_file.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int),
                                     C.POINTER(C.c_int)]

@@ -169,3 +169,16 @@ def test_gzip_large_parallel_crc(tmp_path):
     # the member boundary exactly on a piece boundary
     got, tr, kind = read_file(z, 3 << 20, 4, out_cap=20 << 20)
     assert got == data and not tr
+
+
+def test_crc32_slicing_matches_zlib():
+    from emu_helper import lib
+    rng = random.Random(7)
+    for n in [0, 1, 2, 15, 16, 17, 31, 32, 33, 255, 1000, 65537, 1 << 20]:
+        data = bytes(rng.getrandbits(8) for _ in range(min(n, 70000))) * (1 if n <= 70000 else n // 70000 + 1)
+        data = data[:n]
+        for off in (0, 1, 3, 7):
+            d = data[off:]
+            assert lib().emu_crc32(0, d, len(d)) == (zlib.crc32(d) & 0xFFFFFFFF)
+            half = len(d) // 3
+            assert lib().emu_crc32(lib().emu_crc32(0, d[:half], half), d[half:], len(d) - half) == (zlib.crc32(d) & 0xFFFFFFFF)
