@@ -16,7 +16,7 @@ STAT_NAMES = ("reads", "perfect_counter", "imperfect_counter", "non_aligned_coun
 
 EXPORTS = (
     "f2q_version", "f2q_create", "f2q_destroy", "f2q_last_error", "f2q_set_features", "f2q_count_block",
-    "f2q_count_file", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
+    "f2q_count_file", "f2q_count_file_shard", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
     "f2q_block_free", "f2q_synth_fastq", "f2q_synth_library", "f2q_reset_counts", "f2q_read_counts",
     "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base", "f2q_synth_guides",
 )
@@ -133,6 +133,7 @@ def load(path=None):
     L.f2q_set_features.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32), C.c_uint32]
     L.f2q_count_block.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Timing)]
     L.f2q_count_file.argtypes = [vp, C.c_char_p, C.POINTER(Timing)]
+    L.f2q_count_file_shard.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(Timing)]
     L.f2q_synth_create.argtypes = [vp, C.POINTER(Synth), C.POINTER(vp)]
     L.f2q_block_from_fastq.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     L.f2q_count_resident.argtypes = [vp, vp, C.POINTER(Timing)]
@@ -260,6 +261,15 @@ class Counter:
         """Counts a whole .fastq / .gz file.  Returns (timing dict, truncated flag)."""
         t = Timing()
         rc = self._L.f2q_count_file(self._h, os.fsencode(path), C.byref(t))
+        if rc == F2Q_ETRUNCATED:
+            return t.as_dict(), True
+        self._check(rc)
+        return t.as_dict(), False
+
+    def count_file_shard(self, path, rank, world):
+        """This rank's share of a file that `world` processes count together.  Returns (timing dict, truncated flag)."""
+        t = Timing()
+        rc = self._L.f2q_count_file_shard(self._h, os.fsencode(path), rank, world, C.byref(t))
         if rc == F2Q_ETRUNCATED:
             return t.as_dict(), True
         self._check(rc)

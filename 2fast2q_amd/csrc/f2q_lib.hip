@@ -916,9 +916,50 @@ static PinnedPool g_pinned;
 // reads_counter's file half (fast2q.py:560-578).  A reader thread (f2q_reader.h: parallel pread / parallel BGZF
 // inflate / gzread) fills one pinned buffer while the device frames, packs and counts the other; whole lines only
 // are handed over, the unconsumed tail (a partial record) is carried in front of the next piece.
-extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
+// The framing of a piece that another rank counts: how many records it holds and where the last complete one ends
+// (the same verdict block_from_text_device reaches on the device), from a newline census by the worker pool.
+static size_t skip_piece(const uint8_t *p, size_t n, int threads, uint64_t *n_records)
 {
-    if (!c || !path) return F2Q_EINVAL;
+    *n_records = 0;
+    if (n == 0) return 0;
+    const size_t slice_min = (size_t)1 << 20;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / slice_min));
+    std::vector<uint64_t> cnt((size_t)T, 0);
+    auto bounds = [&](int t, size_t &a, size_t &b) { a = n * (size_t)t / (size_t)T; b = n * (size_t)(t + 1) / (size_t)T; };
+    auto work = [&](int t) {
+        size_t a, b; bounds(t, a, b);
+        uint64_t k = 0;
+        for (size_t i = a; i < b; i++) k += (p[i] == 0x0a);
+        cnt[(size_t)t] = k;
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    uint64_t n_nl = 0; for (uint64_t k : cnt) n_nl += k;
+    const uint64_t n_lines = n_nl + (p[n - 1] != 0x0a ? 1 : 0);
+    const uint64_t n_rec = n_lines / 4;
+    *n_records = n_rec;
+    if (n_rec == 0) return 0;
+    if (4 * n_rec > n_nl) return n;                       // the last record's last line has no newline: everything
+    // position after the (4 * n_rec)-th newline
+    uint64_t want = 4 * n_rec, seen = 0;
+    for (int t = 0; t < T; t++) {
+        if (seen + cnt[(size_t)t] >= want) {
+            size_t a, b; bounds(t, a, b);
+            for (size_t i = a; i < b; i++) if (p[i] == 0x0a && ++seen == want) return i + 1;
+        }
+        seen += cnt[(size_t)t];
+    }
+    return n;
+}
+
+static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t world, f2q_timing *t)
+{
+    if (!c || !path || world == 0 || rank >= world) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
     size_t CH = (size_t)256 << 20;                 // bytes of text per piece; F2Q_FILE_CHUNK overrides (tests)
     { const char *e = getenv("F2Q_FILE_CHUNK"); if (e && atol(e) >= 4096) CH = (size_t)atol(e); }
@@ -953,6 +994,7 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
     int rc = F2Q_OK;
     std::vector<uint8_t> carry, big;
     double wait_ms = 0;
+    uint32_t piece_no = 0;                         // pieces are dealt to the ranks round robin
     for (;;) {
         Piece pc;
         { const double w0 = now_ms(); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !ready.empty(); }); pc = ready.front(); ready.pop_front(); wait_ms += now_ms() - w0; }
@@ -971,12 +1013,18 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
         size_t used = 0;
         if (have) {
             f2q_timing one; memset(&one, 0, sizeof one);
-            if (eof) { rc = f2q_count_block(c, base, have, &used, &one); used = have; }   // trailing partial record is dropped (:392)
-            else {
-                size_t cut = have;                 // only whole lines: a line is never split between blocks
-                while (cut > 0 && base[cut - 1] != 0x0a) cut--;
-                if (cut) rc = f2q_count_block(c, base, cut, &used, &one);
+            size_t cut = have;                     // only whole lines: a line is never split between blocks
+            if (!eof) while (cut > 0 && base[cut - 1] != 0x0a) cut--;
+            if (cut) {
+                if (piece_no % world == rank) rc = f2q_count_block(c, base, cut, &used, &one);
+                else {                             // another rank's piece: only its framing matters here
+                    uint64_t n_rec = 0;
+                    used = skip_piece(base, cut, src.n_threads, &n_rec);
+                    c->reads_seen += n_rec;
+                }
+                piece_no++;
             }
+            if (eof) used = have;                  // trailing partial record is dropped (:392)
             sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
             sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
         }
@@ -993,6 +1041,15 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t)
     if (rc) return rc;
     if (src.truncated()) return fail(c, F2Q_ETRUNCATED, std::string(path) + " is an incomplete or corrupted gzip file");
     return F2Q_OK;
+}
+
+extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t) { return count_file_impl(c, path, 0, 1, t); }
+
+// one process per GPU on the same file: every rank streams the whole file (the framing is global), counts the
+// pieces k with k % world == rank on its device and only takes a newline census of the others
+extern "C" int f2q_count_file_shard(f2q_ctx *c, const char *path, uint32_t rank, uint32_t world, f2q_timing *t)
+{
+    return count_file_impl(c, path, rank, world, t);
 }
 
 // ---- synthetic workload ---------------------------------------------------------------------------

@@ -103,7 +103,7 @@ def _counter_kwargs(param):
                 start=param['start'], upstream=param['upstream'], downstream=param['downstream'],
                 miss_search_up=param['miss_search_up'], miss_search_down=param['miss_search_down'],
                 qual_up=param['qual_up'], qual_down=param['qual_down'],
-                device=int(param.get('device', os.environ.get("LOCAL_RANK", 0))))
+                device=int(param.get('device', os.environ.get("F2Q_DEVICE", os.environ.get("LOCAL_RANK", 0)))))
 
 
 def reads_counter(i, raw, features, param, reads_stats, preprocess=False):

@@ -91,7 +91,9 @@ def iter_record_blocks(path, block_bytes=BLOCK_BYTES):
 
 def count_file_sharded(ctx, path, w, block_bytes=BLOCK_BYTES):
     """rank w.rank counts its blocks of `path` into ctx; returns the truncated-gzip flag"""
-    truncated = False
+    if hasattr(ctx, "count_file_shard"):           # the library streams, frames and deals the pieces itself
+        return ctx.count_file_shard(path, w.rank, w.size)[1]
+    truncated = False                              # contexts without it (the CPU test-suite's stand-in): Python framing
     for index, first_read, block, trunc in iter_record_blocks(path, block_bytes):
         truncated = truncated or trunc
         if block and shard_of(index, w) == w.rank:

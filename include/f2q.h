@@ -121,6 +121,12 @@ int f2q_set_features(f2q_ctx *ctx, const char *seqs, const uint32_t *offs, uint3
 int f2q_count_block(f2q_ctx *ctx, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_timing *t);
 /* reads_counter's file half (fast2q.py:560-578): plain or .gz FASTQ by path. */
 int f2q_count_file(f2q_ctx *ctx, const char *path, f2q_timing *t);
+/* The same file counted by `world` processes, one per GPU (replaces the chunk pool of
+ * single_file_reads_binner, fast2q.py:447-512): every rank streams the whole file -- the 4-line framing is
+ * global -- counts the pieces k with k % world == rank on its device and only frames the others (a newline
+ * census on the host); read indices stay global, so Extract+Count tables merge by key with min(first).
+ * The sum over the ranks of counts and stats equals f2q_count_file's. */
+int f2q_count_file_shard(f2q_ctx *ctx, const char *path, uint32_t rank, uint32_t world, f2q_timing *t);
 
 /* Device-resident blocks: the roofline entry points.  f2q_synth_create generates the §8(d)
  * reads on the device straight into the packed tile layout; f2q_block_from_fastq packs a host

@@ -1,0 +1,34 @@
+# two ranks of the command line on ONE GPU (gloo for the reduction, both contexts on device 0): the compiled table
+# must equal the single-process one.  A rehearsal of the multi-process launch of INTEGRATION.md, not a benchmark.
+# Every step has a hard timeout and writes under gpurun_out/rehearse/.
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/rehearse; rm -rf $O; mkdir -p $O
+W=$(mktemp -d)
+python - "$W" <<'PY'
+import sys, os, gzip
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import synth
+from conftest import bgzf_bytes
+w = sys.argv[1]
+guides = synth.make_library(300, 20, 9)
+os.makedirs(w + "/in")
+open(w + "/g.csv", "w").write("".join(f"g{i},{g}\n" for i, g in enumerate(guides)))
+for k, (n, kind) in enumerate([(40000, "plain"), (30000, "gzip"), (20000, "bgzf")]):
+    fq = synth.make_fastq(synth.Spec(seed=100 + k, n_reads=n, read_len=120), guides)
+    p = f"{w}/in/s{k}.fastq" + ("" if kind == "plain" else ".gz")
+    open(p, "wb").write(fq if kind == "plain" else gzip.compress(fq, 1) if kind == "gzip" else bgzf_bytes(fq))
+PY
+echo "inputs ready" | tee $O/progress.txt
+export F2Q_FILE_CHUNK=300000 PYTHONFAULTHANDLER=1 GLOO_SOCKET_IFNAME=lo
+timeout -s ABRT -k 5 90 python -m 2fast2q_amd -c --s $W/in --g $W/g.csv --o $W/one --fn one --m 1 --pb > $O/one.log 2>&1
+echo "single process rc=$?" | tee -a $O/progress.txt
+for r in 0 1; do
+  RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29521 F2Q_DEVICE=0 F2Q_DIST_BACKEND=gloo \
+    timeout -s ABRT -k 5 90 python -m 2fast2q_amd -c --s $W/in --g $W/g.csv --o $W/two --fn two --m 1 --pb > $O/rank$r.log 2>&1 &
+done
+wait
+echo "two ranks done" | tee -a $O/progress.txt
+A=$(find $W/one -name "one.csv" | head -1); B=$(find $W/two -name "two.csv" | head -1)
+if [ -n "$A" ] && [ -n "$B" ] && cmp $A $B; then echo "compiled tables identical: $(wc -l < $A) rows" | tee -a $O/progress.txt; else echo "compiled tables differ or missing: [$A] [$B]" | tee -a $O/progress.txt; tail -30 $O/rank0.log; tail -30 $O/rank1.log; fi
+for s in s0 s1 s2; do a=$(find $W/one -name "${s}_reads.csv" | head -1); b=$(find $W/two -name "${s}_reads.csv" | head -1); [ -n "$a" ] && [ -n "$b" ] && tail -n +2 $a | cmp - <(tail -n +2 $b) && echo "$s reads table identical" | tee -a $O/progress.txt; done
+true

@@ -7,7 +7,7 @@ import os
 import pytest
 
 import synth
-from conftest import ROOT, bgzf_bytes, pkg
+from conftest import ROOT, bgzf_bytes, pkg, sprinkle_symbols
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -84,6 +84,42 @@ def test_empty_and_tiny_files(tmp_path):
     with pytest.raises(pkg().binding.F2QError):
         with pkg().Counter(features=guides) as c:
             c.count_file(str(tmp_path / "does_not_exist.fastq"))
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_count_file_shard_sums_to_the_whole(tmp_path, monkeypatch, kind, world):
+    """f2q_count_file_shard: `world` contexts (one per rank) on the same file; pieces dealt round robin, framing global.
+    Counter mode: the rank vectors add up to the oracle's; Extract+Count: tables merged by key (sum, min first-read)
+    give the oracle's dict in its order.  Small pieces so that records straddle piece and rank boundaries."""
+    sharding = importlib.import_module("2fast2q_amd.sharding")
+    monkeypatch.setenv("F2Q_FILE_CHUNK", "50000")
+    guides = synth.make_library(150, 20, 5)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=31, n_reads=12000, read_len=101), guides), 3, rate=0.004)
+    fq = fq.replace(b"\n", b"\r\n", 500) + b"@tail\nACGT"              # CRLF lines and a partial record at the end
+    path = tmp_path / ("s.fastq" if kind == "plain" else "s.fastq.gz")
+    path.write_bytes({"plain": fq, "gzip": gzip.compress(fq, 1), "bgzf": bgzf_bytes(fq, block=30000)}[kind])
+    for kw in (dict(miss=1), dict(mode="EC", start="5", length=18), dict(mode="EC", upstream="ACGT", length=9)):
+        feats = guides if "mode" not in kw else None
+        orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)] if feats else None, **kw)
+        orc.count_fastq(fq)
+        tot_counts, tot_stats, tables, reads = None, [0] * 5, [], 0
+        for rank in range(world):
+            with pkg().Counter(features=feats, **kw) as c:
+                t, trunc = c.count_file_shard(str(path), rank, world)
+                assert not trunc
+                counts, stats = c.read_counts()
+                reads += t["reads"]
+                tot_stats = [a + int(b) for a, b in zip(tot_stats, stats)]
+                if feats:
+                    tot_counts = list(counts) if tot_counts is None else [a + b for a, b in zip(tot_counts, counts)]
+                else:
+                    tables.append(c.ec_results())
+        assert tot_stats == orc.stats() and reads == orc.stats()[0]
+        if feats:
+            assert tot_counts == orc.counts()
+        else:
+            assert [(k, n) for k, n, _ in sharding.merge_ec_tables(tables)] == list(zip(orc.keys(), orc.counts()))
 
 
 def test_cli_test_mode_end_to_end(tmp_path, monkeypatch):
