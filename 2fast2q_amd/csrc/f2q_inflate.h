@@ -58,7 +58,8 @@ struct Inflater {
     static constexpr uint32_t F_LIT = 1u << 15, F_EOB = 1u << 14, F_SUB = 1u << 13, F_BAD = 1u << 12;
     static constexpr uint32_t WSIZE = 32768;
 
-    // entry: bits 0-7 code length of this stage, 8-11 extra bits / sub-table index bits, 12-15 flags, 16-31 value
+    // entry: bits 0-7 bits to drop at this stage (code length + extra bits), 8-11 extra bits / sub-table index bits,
+    // 12-15 flags, 16-31 value (literal, length / distance base, sub-table start)
     uint32_t lt[LT_CAP], dt[DT_CAP];
     uint64_t bb = 0; int bc = 0;
     const uint8_t *in = nullptr, *in_end = nullptr;
@@ -94,14 +95,14 @@ struct Inflater {
         if (sym < 256) return ((uint32_t)sym << 16) | F_LIT | (uint32_t)len;
         if (sym == 256) return F_EOB | (uint32_t)len;
         if (sym > 285) return F_BAD | (uint32_t)len;
-        return ((uint32_t)base[sym - 257] << 16) | ((uint32_t)xb[sym - 257] << 8) | (uint32_t)len;
+        return ((uint32_t)base[sym - 257] << 16) | ((uint32_t)xb[sym - 257] << 8) | (uint32_t)(len + xb[sym - 257]);
     }
     static uint32_t dist_entry(int sym, int len)
     {
         static const uint16_t base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
         static const uint8_t xb[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
         if (sym > 29) return F_BAD | (uint32_t)len;
-        return ((uint32_t)base[sym] << 16) | ((uint32_t)xb[sym] << 8) | (uint32_t)len;
+        return ((uint32_t)base[sym] << 16) | ((uint32_t)xb[sym] << 8) | (uint32_t)(len + xb[sym]);
     }
 
     // canonical code -> two-level table.  Rules as zlib's inflate_table: over-subscribed sets are rejected, incomplete
@@ -292,6 +293,7 @@ struct Inflater {
                     refill_fast();
                     uint32_t e = lt[bb & ((1u << LT_BITS) - 1u)];
                     if (__builtin_expect(e & F_SUB, 0)) { bb >>= LT_BITS; bc -= LT_BITS; e = lt[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))]; }
+                    const uint64_t saved = bb;
                     bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
                     if (e & F_LIT) {
                         *out++ = (uint8_t)(e >> 16);
@@ -312,16 +314,16 @@ struct Inflater {
                         continue;
                     }
                     if (e & (F_EOB | F_BAD)) { if (e & F_BAD) err = true; else eob = true; break; }
+                    // code and extra bits leave the buffer in one shift; the extra bits are read from the saved copy
                     const uint32_t xb = (e >> 8) & 15u;
-                    uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xb) - 1u));
-                    bb >>= xb; bc -= (int)xb;
+                    uint32_t len = (e >> 16) + (uint32_t)((saved >> ((e & 0xFF) - xb)) & ((1u << xb) - 1u));
                     uint32_t d = dt[bb & ((1u << DT_BITS) - 1u)];
-                    if (d & F_SUB) { bb >>= DT_BITS; bc -= DT_BITS; d = dt[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))]; }
+                    if (__builtin_expect(d & F_SUB, 0)) { bb >>= DT_BITS; bc -= DT_BITS; d = dt[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))]; }
                     if (d & F_BAD) { err = true; break; }
+                    const uint64_t dsaved = bb;
                     bb >>= (d & 0xFF); bc -= (int)(d & 0xFF);
                     const uint32_t dxb = (d >> 8) & 15u;
-                    const uint32_t dist = (d >> 16) + (uint32_t)(bb & ((1u << dxb) - 1u));
-                    bb >>= dxb; bc -= (int)dxb;
+                    const uint32_t dist = (d >> 16) + (uint32_t)((dsaved >> ((d & 0xFF) - dxb)) & ((1u << dxb) - 1u));
                     const size_t have = (size_t)(out - out_begin);
                     if (dist > have) {
                         if (dist - have > win_len) { err = true; break; }
@@ -331,7 +333,8 @@ struct Inflater {
                     const uint8_t *src = out - dist;
                     if (dist >= 8) {
                         uint8_t *dst = out; const uint8_t *s = src; uint8_t *const end = out + len;
-                        do { store64(dst, load64(s)); dst += 8; s += 8; } while (dst < end);
+                        store64(dst, load64(s)); store64(dst + 8, load64(s + 8));           // most matches are short
+                        if (len > 16) { dst += 16; s += 16; do { store64(dst, load64(s)); dst += 8; s += 8; } while (dst < end); }
                     } else if (dist == 1) {
                         const uint64_t v = 0x0101010101010101ull * src[0];
                         uint8_t *dst = out; uint8_t *const end = out + len;
@@ -354,7 +357,7 @@ struct Inflater {
                         e = lt[(e >> 16) + (uint32_t)((bb >> LT_BITS) & ((1u << ((e >> 8) & 15u)) - 1u))];
                     }
                     if (e & F_BAD) { err = true; break; }
-                    used += (int)(e & 0xFF);
+                    used += (int)(e & 0xFF);                               // code and extra bits
                     if (used > bc) { err = true; break; }                  // the stream ends inside a code
                     if (e & F_LIT) {
                         if (out == out_end) { rc = OUT_FULL; break; }      // nothing consumed: the symbol is decoded again next time
@@ -365,9 +368,7 @@ struct Inflater {
                     }
                     if (e & F_EOB) { bb >>= used; bc -= used; eob = true; break; }
                     const uint32_t xb = (e >> 8) & 15u;
-                    if (used + (int)xb > bc) { err = true; break; }
-                    uint32_t len = (e >> 16) + (uint32_t)((bb >> used) & ((1u << xb) - 1u));
-                    used += (int)xb;
+                    uint32_t len = (e >> 16) + (uint32_t)((bb >> (used - (int)xb)) & ((1u << xb) - 1u));
                     bb >>= used; bc -= used;                              // length taken; 15 + 13 more bits at most for the distance
                     refill_safe();
                     uint32_t d = dt[bb & ((1u << DT_BITS) - 1u)];
@@ -380,9 +381,8 @@ struct Inflater {
                     if (d & F_BAD) { err = true; break; }
                     used += (int)(d & 0xFF);
                     const uint32_t dxb = (d >> 8) & 15u;
-                    if (used + (int)dxb > bc) { err = true; break; }
-                    const uint32_t dist = (d >> 16) + (uint32_t)((bb >> used) & ((1u << dxb) - 1u));
-                    used += (int)dxb;
+                    if (used > bc) { err = true; break; }
+                    const uint32_t dist = (d >> 16) + (uint32_t)((bb >> (used - (int)dxb)) & ((1u << dxb) - 1u));
                     bb >>= used; bc -= used;
                     if (dist > (size_t)(out - out_begin) + win_len) { err = true; break; }
                     while (len && out < out_end) { *out = back_byte(out_begin, out, dist); out++; len--; }
