@@ -883,7 +883,7 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
 // ---- file streaming -------------------------------------------------------------------------------
 // Page-locked staging buffers are expensive to create (tens of ms per 256 MiB) and every file needs two, so
 // they are kept in a small process-wide pool between files (and between contexts: --cp runs several at once).
-struct PinBuf { uint8_t *p = nullptr; size_t cap = 0; };
+struct PinBuf { uint8_t *p = nullptr; size_t cap = 0; bool pageable = false; };
 struct PinnedPool {
     std::mutex mu;
     std::vector<PinBuf> idle;
@@ -898,17 +898,22 @@ struct PinnedPool {
                 if (idle[i].cap >= cap && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
             if (best < idle.size()) { out = idle[best]; idle_bytes -= out.cap; idle.erase(idle.begin() + (ptrdiff_t)best); return true; }
         }
-        out.p = nullptr; out.cap = cap;
-        return hipHostMalloc((void **)&out.p, cap, hipHostMallocPortable) == hipSuccess;
+        out.p = nullptr; out.cap = cap; out.pageable = false;
+        if (hipHostMalloc((void **)&out.p, cap, hipHostMallocPortable) == hipSuccess) return true;
+        (void)hipGetLastError();                          // no page-locked memory to be had: ordinary memory works too,
+        out.pageable = true;                              // the copies to the device are just staged by the runtime
+        out.p = (uint8_t *)malloc(cap);
+        return out.p != nullptr;
     }
     void release(PinBuf &b)
     {
         if (!b.p) return;
         {
             std::lock_guard<std::mutex> g(mu);
-            if (idle_bytes + b.cap <= KEEP_BYTES && idle.size() < 8) { idle.push_back(b); idle_bytes += b.cap; b = PinBuf(); return; }
+            if (!b.pageable && idle_bytes + b.cap <= KEEP_BYTES && idle.size() < 8) { idle.push_back(b); idle_bytes += b.cap; b = PinBuf(); return; }
         }
-        (void)hipHostFree(b.p); b = PinBuf();
+        if (b.pageable) free(b.p); else (void)hipHostFree(b.p);
+        b = PinBuf();
     }
 };
 static PinnedPool g_pinned;
