@@ -45,6 +45,8 @@ struct f2q_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    hipStream_t copy_stream = nullptr;   // f2q_count_file: the text of the next piece travels while this one is counted
+    hipEvent_t ev_copy = nullptr;
     RunDev run_h{};
     RunDev *run_d = nullptr;
     PackPlan plan{};
@@ -298,6 +300,8 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
     if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -721,24 +725,33 @@ static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_bloc
 
 // FASTQ text -> resident block, framing and packing done by the device (k_nl_count .. k_pack).  Handles up to
 // 2 GiB of text per call; *consumed = bytes up to the end of the last complete record.
-static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_block **out)
+// text that is already (on its way) in device memory: `buf` is the allocation (it becomes the block's), `text` the
+// 16-byte aligned start of the FASTQ bytes inside it, with room for the census padding behind them
+struct DevText { void *buf = nullptr; size_t cap = 0; uint8_t *text = nullptr; uint8_t last_byte = 0; };
+
+static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_block **out,
+                                  const DevText *pre = nullptr)
 {
     *out = nullptr; *consumed = 0;
     f2q_block *b = new f2q_block();
-    if (nbytes == 0) { *out = b; return F2Q_OK; }    // an empty buffer is an empty block
+    if (pre) b->allocs.push_back(pre->buf);
+    if (nbytes == 0) { if (pre) free_all(c, b->allocs); *out = b; return F2Q_OK; }    // an empty buffer is an empty block
     std::vector<void *> tmp;                         // scratch freed before returning
     int rc = F2Q_OK;
     auto bail = [&](int code) { free_all(c, tmp); free_all(c, b->allocs); delete b; return code; };
     const uint32_t n_chunks = (uint32_t)((nbytes + F2Q_NL_CHUNK - 1) / F2Q_NL_CHUNK);
     const size_t padded = (size_t)n_chunks * F2Q_NL_CHUNK + 16;
     uint8_t *d_text; uint32_t *d_cc, *d_cp;
-    if ((rc = dev_alloc(c, padded, &d_text, b->allocs))) return bail(rc);
+    if (pre) {
+        d_text = pre->text;
+        if ((size_t)(d_text - (uint8_t *)pre->buf) + padded > pre->cap) { fail(c, F2Q_EINVAL, "staged text buffer too small"); return bail(F2Q_EINVAL); }
+    } else if ((rc = dev_alloc(c, padded, &d_text, b->allocs))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)n_chunks + 1, &d_cc, tmp, 0))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)n_chunks + 1, &d_cp, tmp))) return bail(rc);
 #define ING(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, F2Q_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); return bail(F2Q_EHIP); } } while (0)
     ING(hipMemsetAsync(d_text + nbytes, 0, padded - nbytes, c->stream));
     const double tc0 = now_ms();
-    ING(hipMemcpyAsync(d_text, fastq, nbytes, hipMemcpyHostToDevice, c->stream));
+    if (!pre) ING(hipMemcpyAsync(d_text, fastq, nbytes, hipMemcpyHostToDevice, c->stream));
     if (c->trace) { ING(hipStreamSynchronize(c->stream)); c->tr_copy += now_ms() - tc0; }
     hipLaunchKernelGGL(k_nl_count, dim3(n_chunks), dim3(256), 0, c->stream, d_text, (uint64_t)nbytes, d_cc);
     ING(hipGetLastError());
@@ -750,7 +763,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     uint32_t n_newlines = 0;
     ING(hipMemcpyAsync(&n_newlines, d_cp + n_chunks, 4, hipMemcpyDeviceToHost, c->stream));
     ING(hipStreamSynchronize(c->stream));
-    const bool open_tail = nbytes > 0 && fastq[nbytes - 1] != '\n';
+    const bool open_tail = nbytes > 0 && (pre ? pre->last_byte : fastq[nbytes - 1]) != '\n';
     const uint64_t n_lines = (uint64_t)n_newlines + (open_tail ? 1 : 0);
     const uint32_t n_rec = (uint32_t)(n_lines / 4);
     uint32_t *d_ls;
@@ -833,6 +846,29 @@ extern "C" int f2q_block_from_fastq(f2q_ctx *c, const uint8_t *fastq, size_t nby
     return block_from_records(c, recs, out);
 }
 
+// one window of text (at most 1 GiB: the device packer indexes it with 32 bits): frame, pack, count, free
+static int count_window(f2q_ctx *c, const uint8_t *fastq, size_t take, const DevText *pre, size_t *used_out, f2q_timing *one)
+{
+    f2q_block *b = nullptr; size_t used = 0;
+    int rc;
+    const double t0 = now_ms();
+    if (!c->host_pack || pre) rc = block_from_text_device(c, fastq, take, &used, &b, pre);
+    else {
+        std::vector<Rec> recs;
+        used = frame_fastq(fastq, take, recs);
+        rc = recs.empty() ? F2Q_OK : block_from_records(c, recs, &b);
+    }
+    if (rc) return rc;
+    const double t1 = now_ms();
+    if (b && b->n_reads) rc = launch_block(c, b, one);
+    if (c->trace) (void)hipStreamSynchronize(c->stream);
+    const double t2 = now_ms();
+    if (b) f2q_block_free(c, b);
+    c->tr_frame += t1 - t0; c->tr_count += t2 - t1; c->tr_free += now_ms() - t2;
+    *used_out = used;
+    return rc;
+}
+
 extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_timing *t)
 {
     if (!c || (!fastq && nbytes)) return F2Q_EINVAL;
@@ -845,22 +881,9 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
     while (pos < nbytes) {
         // the device packer indexes the text with 32 bits: feed it at most 1 GiB at a time (record aligned by itself)
         const size_t take = std::min<size_t>(nbytes - pos, (size_t)1 << 30);
-        f2q_block *b = nullptr; size_t used = 0;
-        const double t0 = now_ms();
-        if (!c->host_pack) rc = block_from_text_device(c, fastq + pos, take, &used, &b);
-        else {
-            std::vector<Rec> recs;
-            used = frame_fastq(fastq + pos, take, recs);
-            rc = recs.empty() ? F2Q_OK : block_from_records(c, recs, &b);
-        }
-        if (rc) return rc;
+        size_t used = 0;
         f2q_timing one; memset(&one, 0, sizeof one);
-        const double t1 = now_ms();
-        if (b && b->n_reads) rc = launch_block(c, b, t ? &one : nullptr);
-        if (c->trace) (void)hipStreamSynchronize(c->stream);
-        const double t2 = now_ms();
-        if (b) f2q_block_free(c, b);
-        c->tr_frame += t1 - t0; c->tr_count += t2 - t1; c->tr_free += now_ms() - t2;
+        rc = count_window(c, fastq + pos, take, nullptr, &used, t ? &one : nullptr);
         if (rc) return rc;
         sum.kernel_ms += one.kernel_ms; sum.reads += one.reads; sum.fast_reads += one.fast_reads;
         sum.general_reads += one.general_reads; sum.launches += one.launches;
@@ -888,7 +911,7 @@ struct PinnedPool {
     std::mutex mu;
     std::vector<PinBuf> idle;
     size_t idle_bytes = 0;
-    static constexpr size_t KEEP_BYTES = (size_t)1200 << 20;
+    static constexpr size_t KEEP_BYTES = (size_t)1600 << 20;
     bool acquire(size_t cap, PinBuf &out)
     {
         {
@@ -974,17 +997,19 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
     if (src.kind == TextSource::PLAIN && src.regular) CH = std::min<size_t>(CH, std::max<size_t>(src.file_size, 4096));
     else if (src.regular) CH = std::min<size_t>(CH, std::max<size_t>(src.file_size * 16, (size_t)4 << 20));
     const double tr_a = now_ms();
-    PinBuf buf[2];
-    auto drop = [&]() { g_pinned.release(buf[0]); g_pinned.release(buf[1]); };
-    if (!g_pinned.acquire(HEAD + CH, buf[0]) || !g_pinned.acquire(HEAD + CH, buf[1])) { drop(); return fail(c, F2Q_ENOMEM, "cannot allocate the pinned read buffers"); }
+    // three staging buffers: one being counted, one ready (its text already travelling to the device), one being read
+    constexpr int NSLOT = 3;
+    PinBuf buf[NSLOT];
+    auto drop = [&]() { for (auto &b : buf) g_pinned.release(b); };
+    for (auto &b : buf) if (!g_pinned.acquire(HEAD + CH, b)) { drop(); return fail(c, F2Q_ENOMEM, "cannot allocate the read buffers"); }
     const double tr_b = now_ms();
 
     struct Piece { int slot; size_t n; };
     std::mutex mu; std::condition_variable cv;
-    std::deque<Piece> ready; bool slot_free[2] = {true, true}; bool stop = false;
+    std::deque<Piece> ready; bool slot_free[NSLOT]; for (bool &f : slot_free) f = true; bool stop = false;
     double read_ms = 0;
     std::thread reader([&]() {
-        for (int slot = 0;; slot ^= 1) {
+        for (int slot = 0;; slot = (slot + 1) % NSLOT) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot_free[slot] || stop; }); if (stop) return; slot_free[slot] = false; }
             const double r0 = now_ms();
             const size_t n = src.read(buf[slot].p + HEAD, CH);
@@ -995,6 +1020,40 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
         }
     });
 
+    // The text of piece k+1 is copied to the device (second stream) while piece k is framed, packed and counted.  Its
+    // carried tail is only known once piece k is framed, so the piece lands HEAD bytes into its device buffer and the
+    // tail is put in front of it later; the text then starts wherever HEAD - tail falls, and the up to 15 bytes between
+    // the 16-byte boundary below it and the text are filled with 'x': they lengthen the first line, which is a record's
+    // header line and is never looked at (fast2q.py:324-328 takes lines 2 and 4 only).
+    struct Staged { void *buf = nullptr; size_t cap = 0; int slot = -1; size_t n = 0; } staged;
+    const bool can_stage = world == 1 && !c->host_pack && !getenv("F2Q_NO_STAGING");
+    if (can_stage && !c->copy_stream) {
+        HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIPC(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    }
+    auto unstage = [&]() {                         // give up a staged copy (after it has landed)
+        if (!staged.buf) return;
+        (void)hipStreamSynchronize(c->copy_stream);
+        std::vector<void *> v{staged.buf}; free_all(c, v);
+        staged = Staged();
+    };
+    auto stage_next = [&]() {
+        if (!can_stage || staged.buf) return;
+        Piece nx{-1, 0};
+        { std::lock_guard<std::mutex> g(mu); if (!ready.empty()) nx = ready.front(); }
+        if (nx.slot < 0 || nx.n == 0) return;
+        void *d = nullptr;
+        const size_t cap = HEAD + nx.n + 2 * (size_t)F2Q_NL_CHUNK + 64;
+        if (dev_get(c, cap, &d) != F2Q_OK) return;     // no memory for it: the piece takes the ordinary path
+        if (hipMemcpyAsync((uint8_t *)d + HEAD, buf[nx.slot].p + HEAD, nx.n, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+            hipEventRecord(c->ev_copy, c->copy_stream) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream);
+            std::vector<void *> v{d}; free_all(c, v);
+            return;
+        }
+        staged.buf = d; staged.cap = cap; staged.slot = nx.slot; staged.n = nx.n;
+    };
+
     f2q_timing sum; memset(&sum, 0, sizeof sum);
     int rc = F2Q_OK;
     std::vector<uint8_t> carry, big;
@@ -1004,6 +1063,12 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
         Piece pc;
         { const double w0 = now_ms(); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !ready.empty(); }); pc = ready.front(); ready.pop_front(); wait_ms += now_ms() - w0; }
         const bool eof = (pc.n == 0);
+        Staged mine;                               // this piece's text, if it was sent ahead
+        if (staged.buf && staged.slot == pc.slot && staged.n == pc.n) {
+            mine = staged; staged = Staged();
+            if (hipStreamWaitEvent(c->stream, c->ev_copy, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); }
+        } else unstage();
+        stage_next();                              // the piece after this one, if the reader has it already
         uint8_t *base; size_t have;
         if (carry.size() <= HEAD) {
             base = buf[pc.slot].p + HEAD - carry.size();
@@ -1021,7 +1086,21 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
             size_t cut = have;                     // only whole lines: a line is never split between blocks
             if (!eof) while (cut > 0 && base[cut - 1] != 0x0a) cut--;
             if (cut) {
-                if (piece_no % world == rank) rc = f2q_count_block(c, base, cut, &used, &one);
+                if (mine.buf && carry.size() <= HEAD) {
+                    const size_t c_len = carry.size(), textoff = HEAD - c_len, al = textoff & ~(size_t)15, lead = textoff - al;
+                    uint8_t *d = (uint8_t *)mine.buf;
+                    hipError_t e = hipSuccess;
+                    if (c_len) e = hipMemcpyAsync(d + textoff, carry.data(), c_len, hipMemcpyHostToDevice, c->stream);
+                    if (e == hipSuccess && lead) e = hipMemsetAsync(d + al, 'x', lead, c->stream);
+                    if (e != hipSuccess) { rc = fail(c, F2Q_EHIP, hipGetErrorString(e)); (void)hipStreamSynchronize(c->stream); std::vector<void *> v{mine.buf}; free_all(c, v); }
+                    else {
+                        DevText pre; pre.buf = mine.buf; pre.cap = mine.cap; pre.text = d + al; pre.last_byte = base[cut - 1];
+                        size_t used_dev = 0;
+                        rc = count_window(c, nullptr, lead + cut, &pre, &used_dev, &one);      // the buffer now belongs to the block
+                        used = used_dev > lead ? used_dev - lead : 0;
+                    }
+                    mine = Staged();
+                } else if (piece_no % world == rank) rc = f2q_count_block(c, base, cut, &used, &one);
                 else {                             // another rank's piece: only its framing matters here
                     uint64_t n_rec = 0;
                     used = skip_piece(base, cut, src.n_threads, &n_rec);
@@ -1029,6 +1108,7 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
                 }
                 piece_no++;
             }
+            if (mine.buf) { (void)hipStreamSynchronize(c->stream); std::vector<void *> v{mine.buf}; free_all(c, v); mine = Staged(); }   // not used after all
             if (eof) used = have;                  // trailing partial record is dropped (:392)
             sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
             sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
@@ -1038,6 +1118,7 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
         cv.notify_all();
         if (rc || eof) break;
     }
+    unstage();
     reader.join();
     drop();
     if (t) *t = sum;
