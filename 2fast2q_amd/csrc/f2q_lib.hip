@@ -1027,6 +1027,7 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
     // header line and is never looked at (fast2q.py:324-328 takes lines 2 and 4 only).
     struct Staged { void *buf = nullptr; size_t cap = 0; int slot = -1; size_t n = 0; } staged;
     const bool can_stage = world == 1 && !c->host_pack && !getenv("F2Q_NO_STAGING");
+    const bool force_stage = getenv("F2Q_FORCE_STAGING") != nullptr;
     if (can_stage && !c->copy_stream) {
         HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPC(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
@@ -1040,7 +1041,11 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
     auto stage_next = [&]() {
         if (!can_stage || staged.buf) return;
         Piece nx{-1, 0};
-        { std::lock_guard<std::mutex> g(mu); if (!ready.empty()) nx = ready.front(); }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (force_stage) cv.wait(lk, [&] { return !ready.empty(); });      // tests: every piece takes this path
+            if (!ready.empty()) nx = ready.front();
+        }
         if (nx.slot < 0 || nx.n == 0) return;
         void *d = nullptr;
         const size_t cap = HEAD + nx.n + 2 * (size_t)F2Q_NL_CHUNK + 64;
@@ -1068,7 +1073,7 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
             mine = staged; staged = Staged();
             if (hipStreamWaitEvent(c->stream, c->ev_copy, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); }
         } else unstage();
-        stage_next();                              // the piece after this one, if the reader has it already
+        if (!eof) stage_next();                    // the piece after this one, if the reader has it already (after the end marker nothing follows)
         uint8_t *base; size_t have;
         if (carry.size() <= HEAD) {
             base = buf[pc.slot].p + HEAD - carry.size();

@@ -236,10 +236,15 @@ def test_console_script_like_the_reference_test(tmp_path):
 
 @pytest.mark.parametrize("gz", ["plain", "gzip", "bgzf"])
 @pytest.mark.parametrize("chunk", ["4096", "65536", "1000003"])
-def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk):
+@pytest.mark.parametrize("staging", ["as_it_comes", "every_piece", "never"])
+def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk, staging):
     """f2q_count_file streams a file in blocks: records and lines that straddle a block boundary, a block that
     holds no complete record, CRLF, and an unterminated last line must not change the counts"""
     monkeypatch.setenv("F2Q_FILE_CHUNK", chunk)
+    # the text of the next piece may travel to the device ahead of time (f2q_count_file): with every piece forced down
+    # that path the carried tail lands at every alignment in front of it; "never" is the plain path
+    if staging == "every_piece": monkeypatch.setenv("F2Q_FORCE_STAGING", "1")
+    if staging == "never": monkeypatch.setenv("F2Q_NO_STAGING", "1")
     guides = synth.make_library(120, 20, 47)
     fq = synth.make_fastq(synth.Spec(seed=80, n_reads=9000, read_len=151), guides)
     fq = fq.replace(b"\n", b"\r\n", 3000)                      # some CRLF line ends
