@@ -1,3 +1,4 @@
+# kernel time and rate of the anchored workloads (config 5a Counter, 5b Extract+Count, 5a without N reads)
 set -e
 B="timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 J='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], round(d["value"]), "Mreads/s kernel_ms", round(d["roofline"]["kernel_ms"],3), "GB/s", round(d["roofline"]["achieved"]))'
