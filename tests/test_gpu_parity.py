@@ -422,10 +422,10 @@ def test_extract_count_fixed_window_gpu(P, start, length, rl):
 
 
 def test_fuzz_kernels_vs_oracle(P):
-    """600 seeded random cases (tests/fuzz_cases.py) through the C ABI: device packer + every kernel family"""
+    """2000 seeded random cases (tests/fuzz_cases.py) through the C ABI: device packer + every kernel family"""
     from fuzz_cases import make_case
     fast = general = 0
-    for seed in range(600):
+    for seed in range(2000):
         kw, feats, fq = make_case(seed)
         o = O.Oracle(features=[(str(i), s) for i, s in enumerate(feats)] if feats is not None else None, **kw)
         used_o = o.count_fastq(fq)
