@@ -119,7 +119,10 @@ int f2q_set_features(f2q_ctx *ctx, const char *seqs, const uint32_t *offs, uint3
  * rstrip(), trailing partial record ignored.  *consumed (optional) = bytes up to the end of the
  * last complete record so a caller can stream a file in blocks. */
 int f2q_count_block(f2q_ctx *ctx, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_timing *t);
-/* reads_counter's file half (fast2q.py:560-578): plain or .gz FASTQ by path. */
+/* reads_counter's file half (fast2q.py:560-578): plain or .gz FASTQ by path (gzip by content; blocked gzip --
+ * BGZF -- is inflated member-parallel).  The file is streamed in pieces by a reader thread while the device
+ * frames, packs and counts.  F2Q_ETRUNCATED: the archive is cut off or damaged; what was readable before the
+ * damage has been counted (the reference returns None for such a file, :580-582; the harness does too). */
 int f2q_count_file(f2q_ctx *ctx, const char *path, f2q_timing *t);
 /* The same file counted by `world` processes, one per GPU (replaces the chunk pool of
  * single_file_reads_binner, fast2q.py:447-512): every rank streams the whole file -- the 4-line framing is
