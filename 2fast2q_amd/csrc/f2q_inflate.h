@@ -289,9 +289,10 @@ struct Inflater {
             if (st == S_CODES) {
                 bool err = false, eob = false;
                 // fast loop: room for the longest match plus a copy overshoot, 8 readable input bytes
+                bool have_e = false; uint32_t e = 0;   // the next entry, looked up while the previous match was being copied
                 while (out_end - out >= 258 + 16 && in_end - in >= 8) {
-                    refill_fast();
-                    uint32_t e = lt[bb & ((1u << LT_BITS) - 1u)];
+                    if (!have_e) { refill_fast(); e = lt[bb & ((1u << LT_BITS) - 1u)]; }
+                    have_e = false;
                     if (__builtin_expect(e & F_SUB, 0)) { bb >>= LT_BITS; bc -= LT_BITS; e = lt[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))]; }
                     const uint64_t saved = bb;
                     bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
@@ -331,6 +332,7 @@ struct Inflater {
                         if (!len) continue;
                     }
                     const uint8_t *src = out - dist;
+                    if (in_end - in >= 8) { refill_fast(); e = lt[bb & ((1u << LT_BITS) - 1u)]; have_e = true; }
                     if (dist >= 8) {
                         uint8_t *dst = out; const uint8_t *s = src; uint8_t *const end = out + len;
                         store64(dst, load64(s)); store64(dst + 8, load64(s + 8));           // most matches are short
