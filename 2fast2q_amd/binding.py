@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("F2Q_LIB_PATH") or os.path.join(_HERE, "lib", "libf2q_
 STAT_NAMES = ("reads", "perfect_counter", "imperfect_counter", "non_aligned_counter", "quality_failed")
 
 EXPORTS = (
-    "f2q_version", "f2q_create", "f2q_destroy", "f2q_last_error", "f2q_set_features", "f2q_count_block",
+    "f2q_version", "f2q_build_id", "f2q_create", "f2q_destroy", "f2q_last_error", "f2q_set_features", "f2q_count_block",
     "f2q_count_file", "f2q_count_file_shard", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
     "f2q_block_free", "f2q_synth_fastq", "f2q_synth_library", "f2q_reset_counts", "f2q_read_counts",
     "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base", "f2q_synth_guides",
@@ -127,6 +127,7 @@ def load(path=None):
     L = C.CDLL(path)
     vp, u64p, i64p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
     L.f2q_version.restype = C.c_int
+    L.f2q_build_id.restype = C.c_char_p
     L.f2q_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.f2q_destroy.argtypes = [vp]; L.f2q_destroy.restype = None
     L.f2q_last_error.argtypes = [vp]; L.f2q_last_error.restype = C.c_char_p
@@ -152,6 +153,11 @@ def load(path=None):
     if path == LIB_PATH:
         _lib = L
     return L
+
+
+def build_id():
+    """the source hash the loaded library was compiled from (include/f2q.h: f2q_build_id)"""
+    return (load().f2q_build_id() or b"").decode()
 
 
 def synth_library(seed, n, length):

@@ -175,6 +175,13 @@ static void free_all(f2q_ctx *c, std::vector<void *> &v)
 
 extern "C" int f2q_version(void) { return F2Q_ABI_VERSION; }
 
+#ifndef F2Q_BUILD_ID
+#define F2Q_BUILD_ID "unknown"
+#endif
+// the "F2Q_BUILD_ID=" prefix lets build() find the id in the file without loading it
+static const char g_build_id[] = "F2Q_BUILD_ID=" F2Q_BUILD_ID;
+extern "C" const char *f2q_build_id(void) { return g_build_id + 13; }
+
 extern "C" const char *f2q_last_error(const f2q_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 extern "C" void *f2q_stream(f2q_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -338,7 +345,7 @@ extern "C" int f2q_reset_counts(f2q_ctx *c)
     HIPC(c, hipMemsetAsync(c->acc_d, 0, c->acc_n * sizeof(unsigned long long), c->stream));
     if (c->prm.mode == 1) { free_all(c, c->ec_allocs); memset(&c->ec, 0, sizeof c->ec); c->ec_slots = 0; }
     c->reads_seen = 0;
-    HIPC(c, hipStreamSynchronize(c->stream));
+    // no host synchronisation: the clear is ordered on the context's stream like every launch and read-back after it
     return F2Q_OK;
 }
 

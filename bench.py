@@ -1,194 +1,447 @@
 #!/usr/bin/env python3
-"""bench.py -- Mreads/s of the 2FAST2Q counting hot path on MI355X (see DESIGN.md §Measurement).
+"""bench.py -- Mreads/s of the 2FAST2Q counting hot path on MI355X (DESIGN.md §5).
 
-A step = one pass of the hot path (Phred mask -> window -> <=m-mismatch match -> count) over one
-device-resident batch of synthetic 150-bp reads, followed by the all-reduce of the
-int64 count vector when N > 1.  Workload = BASELINE.json configs[2], the configuration the metric is
-quoted on: 50M x 150 bp reads vs 10k x 20 bp guides, --m 1 --ph 30, per GPU (weak scaling: config 4 is
-the same per-GPU load on 8 GPUs with a 100k library).
+A step = one whole job over one device-resident batch of synthetic 150-bp reads: zeroed
+accumulators -> Phred mask -> window -> <= m-mismatch match -> counts, followed by the all-reduce of the int64
+count vector when N > 1.
+
+  N = 1   workload cfg3_50M_10k_m1 = BASELINE.json configs[2], the configuration the metric is quoted on
+          (50 M x 150 bp reads vs 10 k x 20 bp guides, --m 1 --ph 30).
+  N > 1   workload cfg4_400M_100k_m1 = configs[3]: 400 M reads x 100 k guides IN TOTAL, split N ways
+          ("scaling": "strong"); one RCCL all-reduce of int64[100 005] ends every step.  `--scaling weak` keeps
+          the per-GPU load of the chosen workload fixed instead.
+
+`--gpus N` with N > 1 outside torchrun starts the N ranks itself (python -m torch.distributed.run, before this
+process touches the GPU); under the driver's torchrun launch it only checks that WORLD_SIZE == N.
+
+The JSON line also carries: `roofline` (bytes the dominant kernel must touch / HIP-event kernel time, measured
+HBM traffic from two rocprofv3 --pmc passes of a child of this script), `verify` (the timed result checked
+against the oracle and the counter identities), `cpu_baseline` / `cpu_baseline_1core` (the oracle on host cores,
+same sample) and `end_to_end` (FASTQ text in host memory / a file -> counts, PCIe inclusive; never `value`).
 """
 import argparse
+import csv
+import glob
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (reads per GPU, guides, miss, synth spec extras, counter extras)
+    # name: total reads (per GPU under weak scaling), guides, --m
     "cfg2_10M_1k_m0": dict(n_reads=10_000_000, n_guides=1000, miss=0, lib_seed=0xF2A5 + 2),
     "cfg3_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 3),
     "cfg4_50M_100k_m1": dict(n_reads=50_000_000, n_guides=100000, miss=1, lib_seed=0xF2A5 + 4),
+    "cfg4_400M_100k_m1": dict(n_reads=400_000_000, n_guides=100000, miss=1, lib_seed=0xF2A5 + 4),
     # config 5: up+guide+down cassette at a uniform offset in [0,100]; --us/--ds anchored search
     "cfg5a_50M_10k_anchor_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True),
     "cfg5b_50M_anchor_ec": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True, ec=True),
 }
 UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
-B_ALG = 188           # algorithmic bytes per 150-bp read: 38 B of 2-bit bases + 150 quality bytes
+B_CONTRACT = 188          # 38 B of 2-bit bases + 150 quality bytes per 150-bp read
 HBM_PEAK_GBS = 8000.0
+SEED = 0xBEEF
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
-    WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams, so it is doubled
-    (MI355X_MICROARCH.md, HBM section).  bench.py cannot collect PMC itself; null when no profile of this workload exists."""
-    path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc.json")
-    try:
-        prof = json.load(open(path))
-    except OSError:
-        return None, None
-    best = None
-    for kern, c in prof.items():
-        if "FETCH_SIZE" in c and (best is None or c["FETCH_SIZE"] > best[1]["FETCH_SIZE"]):
-            best = (kern, c)
-    if best is None:
-        return None, None
-    return (2.0 * best[1]["FETCH_SIZE"] + best[1].get("WRITE_SIZE", 0.0)) * 1024.0, best[0]
-
-
-def cpu_baseline(pkg, guides, miss, seconds_target=15.0):
-    """The oracle (C port of the reference algorithm) timed on this host's cores over a bounded sample of
-    the same workload."""
-    from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    n = 800_000 * max(1, threads // 4)           # ~10 s of host work on a 64-core box
-    with pkg.Counter(features=guides, miss=miss) as c:
-        fq = bytes(c.synth_fastq(seed=1, n_reads=n, read_len=150))
-    feats = [(str(i), s) for i, s in enumerate(guides)]
-    t0 = time.perf_counter()
-    orc = O.count_fastq_parallel(fq, threads, features=feats, miss=miss)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt / 1e6, "unit": "Mreads/s", "cores": threads, "kind": "port",
-            "sample": f"{n} reads of the same synthetic stream, FASTQ text in memory, {threads} threads, "
-                      f"oracle/f2q_oracle.c (dict hit + early-exit all-vs-all with memo caches)",
-            "seconds": dt, "reads_checked": orc.stats()[0]}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3_50M_10k_m1", choices=sorted(WORKLOADS))
-    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (debug)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
+    ap.add_argument("--reads", type=int, default=0, help="override the workload's read count (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline, verify.prefix)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic = null)")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and the strong-scaling N = 1 leg")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL all-reduce path even with one rank (rehearsal)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: ranks may share one GPU, the reduction goes through host tensors (rehearsal on a 1-GPU box)")
     ap.add_argument("--miss", type=int, default=None, help="override --m (experiments)")
     ap.add_argument("--guides", type=int, default=0, help="override the library size (experiments)")
     ap.add_argument("--phred", type=int, default=30, help="override --ph (experiments)")
     ap.add_argument("--ms", type=int, default=1, help="--msu/--msd of the anchored workloads (experiments)")
     ap.add_argument("--read-len", type=int, default=150, help="override the read length (experiments)")
     ap.add_argument("--p-n", type=float, default=0.005, help="share of reads with an N in the window (experiments)")
-    a = ap.parse_args()
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the counting path has no CPU fallback")
-    torch.cuda.set_device(local)
-    use_dist = world > 1 or a.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    pkg = importlib.import_module("2fast2q_amd")
-    w = dict(WORKLOADS[a.workload])
+
+def resolve(a, world):
+    """workload dict + reads this rank holds"""
+    name = a.workload or ("cfg3_50M_10k_m1" if world == 1 else "cfg4_400M_100k_m1")
+    scaling = a.scaling or ("weak" if world == 1 or a.workload else "strong")
+    w = dict(WORKLOADS[name])
     if a.reads:
         w["n_reads"] = a.reads
     if a.miss is not None:
         w["miss"] = a.miss
     if a.guides:
         w["n_guides"] = a.guides
+    return name, scaling, w
+
+
+def make_job(pkg, w, a, device, n, first_read):
+    """(context, resident block) of reads [first_read, first_read + n) of the workload's stream"""
     guides = pkg.binding.synth_library(w["lib_seed"], w["n_guides"], 20)
-    n = w["n_reads"]
     if w.get("anchored"):
-        # the generator needs the library; an EC context has none, so generate through a Counter context's spec
         akw = dict(upstream=UP, downstream=DOWN, miss_search_up=a.ms, miss_search_down=a.ms)
         c = pkg.Counter(features=None if w.get("ec") else guides, mode="EC" if w.get("ec") else "C", miss=w["miss"],
-                        phred=a.phred, device=local, **akw)
-        spec = dict(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=a.read_len, p_n=a.p_n, cassette=True, up=UP,
+                        phred=a.phred, device=device, **akw)
+        spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n, cassette=True, up=UP,
                     down=DOWN, max_offset=100)
         blk = c.synth_create(guides=guides, **spec) if w.get("ec") else c.synth_create(**spec)
     else:
-        c = pkg.Counter(features=guides, miss=w["miss"], phred=a.phred, length=20, start="0", device=local)
-        blk = c.synth_create(seed=0xBEEF, n_reads=n, first_read=rank * n, read_len=a.read_len, p_n=a.p_n)
+        c = pkg.Counter(features=guides, miss=w["miss"], phred=a.phred, length=20, start="0", device=device)
+        spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n)
+        blk = c.synth_create(**spec)
+    return c, blk, guides, spec
+
+
+def required_bytes_per_read(w, read_len):
+    """bytes of a read the dominant kernel cannot avoid fetching.  Fixed --st 0 --l 20: the 2 base words (8 B) and
+    5 quality words (20 B) under the window + the 2-byte length = 30 B (the tile layout keeps the other rows
+    untouched); anchored runs need every base and every quality byte: SURVEY §8(d)'s 188 B at 150 bp."""
+    if w.get("anchored"):
+        return (2 * read_len + 7) // 8 + read_len
+    st, length = 0, 20
+    nb = ((st + length - 1) >> 4) - (st >> 4) + 1
+    nq = ((st + length - 1) >> 2) - (st >> 2) + 1
+    return 4 * nb + 4 * nq + 2
+
+
+# ---- rocprofv3 PMC passes (child of this script, started before this process touches the GPU) -------------------
+def pmc_child(a):
+    """what the profiler wraps: no torch, one context, one resident block, four launches"""
+    pkg = importlib.import_module("2fast2q_amd")
+    name, _, w = resolve(a, 1)
+    c, blk, _, _ = make_job(pkg, w, a, 0, w["n_reads"], 0)
+    for _ in range(4):
+        c.reset()
+        c.count_resident(blk)
+    c.read_counts()
+    blk.free(); c.close()
+
+
+def pmc_traffic(a, dominant):
+    """HBM bytes per launch of the dominant kernel: FETCH_SIZE and WRITE_SIZE (KiB) from two separate rocprofv3 --pmc
+    passes; gfx950 counts a 128-B request of a wide coalesced stream as 64 B in FETCH_SIZE, so the read side is doubled
+    (MI355X_MICROARCH.md, HBM section).  Returns (bytes or None, detail dict)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, {"error": "already running under a profiler"}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="f2q_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", resolve(a, 1)[0], "--phred", str(a.phred),
+             "--ms", str(a.ms), "--read-len", str(a.read_len), "--p-n", str(a.p_n)]
+    if a.reads:
+        child += ["--reads", str(a.reads)]
+    if a.miss is not None:
+        child += ["--miss", str(a.miss)]
+    if a.guides:
+        child += ["--guides", str(a.guides)]
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": f"rocprofv3 --pmc {counter} failed (exit {r.returncode})", "stderr": r.stderr.decode(errors="replace")[-300:]}
+            vals = []
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and dominant in row["Kernel_Name"]:
+                    vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, {"error": f"no {dominant} dispatch in the {counter} pass"}
+            out[counter + "_KiB"] = sum(vals) / len(vals)
+            out["dispatches"] = len(vals)
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return None, {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = (2.0 * out["FETCH_SIZE_KiB"] + out["WRITE_SIZE_KiB"]) * 1024.0
+    out["formula"] = "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, per launch of " + dominant
+    return traffic, out
+
+
+# ---- oracle legs -----------------------------------------------------------------------------------------------
+def oracle_kwargs(w, a):
+    kw = dict(miss=w["miss"], phred=a.phred)
+    if w.get("anchored"):
+        kw.update(upstream=UP, downstream=DOWN, miss_search_up=a.ms, miss_search_down=a.ms)
+        if w.get("ec"):
+            kw["mode"] = "EC"
+    else:
+        kw.update(length=20, start="0")
+    return kw
+
+
+def cpu_legs(pkg, c, w, a, guides, spec):
+    """The oracle (C port of the reference algorithm) on this host's cores over a bounded sample = the first S reads
+    of the bench stream as FASTQ text, and the device result for the same S reads checked against it."""
+    from oracle import oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))              # the GPU box's CPU share for one GPU is 16 cores
+    S = 4_000_000 if w["n_guides"] <= 10000 else 1_000_000
+    S = min(S, spec["n_reads"])
+    fq = bytes(c.synth_fastq(**dict(spec, n_reads=S, first_read=0)))
+    feats = None if w.get("ec") else [(str(i), s) for i, s in enumerate(guides)]
+    kw = oracle_kwargs(w, a)
+    t0 = time.perf_counter()
+    orc = O.count_fastq_parallel(fq, threads, features=feats, **kw) if not w.get("ec") else None
+    if orc is None:
+        orc = O.Oracle(features=None, **kw)
+        orc.count_fastq(fq)
+        threads = 1
+    dt = time.perf_counter() - t0
+    base = {"value": S / dt / 1e6, "unit": "Mreads/s", "cores": threads, "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": f"first {S} reads of the bench stream as FASTQ text in memory, {threads} threads, oracle/f2q_oracle.c "
+                      f"(dict hit + early-exit all-vs-all with memo caches)", "seconds": dt}
+    S1 = max(1, S // 16)
+    fq1 = bytes(c.synth_fastq(**dict(spec, n_reads=S1, first_read=0)))
+    t0 = time.perf_counter()
+    o1 = O.Oracle(features=feats, **kw)
+    o1.count_fastq(fq1)
+    dt1 = time.perf_counter() - t0
+    one = {"value": S1 / dt1 / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port", "sample": f"first {S1} reads, one thread", "seconds": dt1}
+    # the device on the same S reads (resident block generated by the device twin of the generator)
+    c.reset()
+    pre = c.synth_create(**dict(spec, n_reads=S, first_read=0))
+    c.count_resident(pre)
+    counts, stats = c.read_counts()
+    pre.free()
+    ok = list(stats) == orc.stats()
+    if w.get("ec"):
+        ok = ok and [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+    else:
+        ok = ok and list(counts) == orc.counts()
+    prefix = {"reads": S, "stats": [int(v) for v in stats], "equals_oracle": bool(ok)}
+    return base, one, prefix, fq
+
+
+def end_to_end(pkg, c, fq, n_fq):
+    """PCIe-inclusive rates of the host entry points on the same FASTQ text (never `value`)"""
+    out = {"sample_reads": n_fq, "unit": "Mreads/s"}
+    c.reset(); c.count_block(fq[: 1 << 20]); c.reset()
+    t0 = time.perf_counter(); c.count_block(fq); c.read_counts(); dt = time.perf_counter() - t0
+    out["host_text_to_counts"] = n_fq / dt / 1e6
+    d = tempfile.mkdtemp(prefix="f2q_bench_")
+    try:
+        p = os.path.join(d, "x.fastq")
+        with open(p, "wb") as f:
+            f.write(fq)
+        for key in ("plain_file_first", "plain_file_to_counts"):       # second pass: pinned staging buffers already exist
+            c.reset(); t0 = time.perf_counter(); c.count_file(p); c.read_counts(); dt = time.perf_counter() - t0
+            out[key] = n_fq / dt / 1e6
+        import gzip
+        pz = os.path.join(d, "x.fastq.gz")
+        cut = fq[: len(fq) // 4]
+        cut = cut[: cut.rfind(b"\n@r") + 1]
+        nz = cut.count(b"\n") // 4
+        with gzip.open(pz, "wb", compresslevel=1) as f:
+            f.write(cut)
+        c.reset(); t0 = time.perf_counter(); c.count_file(pz); _, st = c.read_counts(); dt = time.perf_counter() - t0
+        out["gzip_file_to_counts"] = nz / dt / 1e6
+        out["gzip_sample_reads"] = int(st[0])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    c.reset()
+    return out
+
+
+def timed_steps(c, blk, steps, warmup, allreduce=None, barrier=None, sync=None):
+    for _ in range(warmup):
+        c.reset(); c.count_resident(blk)
+        if allreduce:
+            allreduce()
+    if barrier:
+        barrier()
+    if sync:
+        sync()
+    kern = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c.reset()                                  # each step is a whole job: zeroed accumulators -> count -> all-reduce
+        kern.append(c.count_resident(blk)["kernel_ms"])   # launches on the context's stream; HIP events of that stream
+        if allreduce:
+            allreduce()
+    if sync:
+        sync()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, sum(kern) / len(kern)
+
+
+def main():
+    a = parse_args()
+    if a.pmc_child:
+        return pmc_child(a)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        # not under a launcher: start the ranks ourselves, before anything here touches the GPU
+        port = os.environ.get("MASTER_PORT", "29511")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    world = int(env_world or "1")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    name, scaling, w = resolve(a, world)
+    dominant = "k_count_anchor" if w.get("anchored") else "k_count_fixed4"
+
+    traffic, traffic_detail = None, {"error": "skipped"}
+    if world == 1 and not a.no_pmc:
+        traffic, traffic_detail = pmc_traffic(a, dominant)      # child processes; this one has not touched the GPU yet
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the counting path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    device = local if a.dist_backend == "nccl" else local % ndev
+    torch.cuda.set_device(device)
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("2fast2q_amd")
+    total = w["n_reads"] * (world if scaling == "weak" else 1)        # reads of the whole job
+    lo, hi = total * rank // world, total * (rank + 1) // world        # this rank's slice of the stream
+    n = hi - lo
+    c, blk, guides, spec = make_job(pkg, w, a, device, n, lo)
     info = blk.info()
 
-    # the device accumulator as a torch tensor, so RCCL can all-reduce it in place
-    ptr, n64 = c.counts_device_ptr()
-
-    class _Arr:
-        __cuda_array_interface__ = {"shape": (n64,), "typestr": "<i8", "data": (ptr, False), "version": 3}
-    acc = torch.as_tensor(_Arr(), device=torch.device("cuda", local))
-    stream = torch.cuda.ExternalStream(c.stream(), device=torch.device("cuda", local))
-
-    def step():
-        t = c.count_resident(blk)          # launches on the context's stream, waits on its HIP events
-        if use_dist:
-            with torch.cuda.stream(stream):
-                dist.all_reduce(acc)
-        return t
-
-    for _ in range(a.warmup):
-        c.reset(); step()
-    kern_ms = []
+    allreduce = barrier = None
+    stream = None
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        c.reset()                              # each step is a whole job: zeroed accumulators -> count -> all-reduce
-        kern_ms.append(step()["kernel_ms"])
-    stream.synchronize()
-    torch.cuda.synchronize()
+        ptr, n64 = c.counts_device_ptr()
+        if a.dist_backend == "nccl":
+            class _Arr:                            # the library's device accumulator as a tensor: reduced in place by RCCL
+                __cuda_array_interface__ = {"shape": (n64,), "typestr": "<i8", "data": (ptr, False), "version": 3}
+            acc = torch.as_tensor(_Arr(), device=torch.device("cuda", device))
+            stream = torch.cuda.ExternalStream(c.stream(), device=torch.device("cuda", device))
+
+            def allreduce():
+                with torch.cuda.stream(stream):    # the stream the counting kernels were launched on
+                    dist.all_reduce(acc)
+        else:
+            holder = {}
+
+            def allreduce():
+                counts, stats = c.read_counts()
+                t = torch.tensor(list(counts) + list(stats), dtype=torch.int64)
+                dist.all_reduce(t)
+                holder["t"] = t
+        barrier = dist.barrier
+
+    def sync():
+        if stream is not None:
+            stream.synchronize()
+        torch.cuda.synchronize()
+
+    dt, k_ms = timed_steps(c, blk, a.steps, a.warmup, allreduce, barrier, sync)
     if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- the timed result is checked: whole-job counters on every rank, oracle on a prefix at N = 1 ---------------
+    if use_dist and a.dist_backend == "gloo":
+        t = holder["t"]
+        counts, stats = t[:-5].numpy(), t[-5:].numpy()
+    else:
+        counts, stats = c.read_counts()
+    stats = [int(v) for v in stats]
+    verify = {"reads": stats[0], "stats": stats, "whole_job_reads_expected": total,
+              "identity_reads_eq_sum_of_outcomes": stats[0] == sum(stats[1:]),
+              "identity_counts_eq_aligned": (w.get("ec") or int(counts.sum()) == stats[1] + stats[2])}
+    assert stats[0] == total, (stats, total)
+    assert verify["identity_reads_eq_sum_of_outcomes"] and verify["identity_counts_eq_aligned"], verify
+    if use_dist:
+        chk = torch.tensor(stats + [int(counts.sum())], dtype=torch.int64, device="cuda" if a.dist_backend == "nccl" else "cpu")
+        mx = chk.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        assert bool((mx == chk).all()), "ranks disagree on the all-reduced result"
+        verify["all_ranks_hold_the_same_result"] = True
+
     if rank == 0:
-        total_reads = n * world * a.steps
-        k_ms = sum(kern_ms) / len(kern_ms)
-        achieved = B_ALG * n / (k_ms * 1e-3) / 1e9
-        traffic, traffic_kernel = measured_traffic(a.workload) if (not a.reads and a.read_len == 150) else (None, None)
+        b_req = required_bytes_per_read(w, a.read_len)
+        achieved = b_req * n / (k_ms * 1e-3) / 1e9
+        contract = B_CONTRACT * a.read_len / 150.0 * n / (k_ms * 1e-3) / 1e9
+        assert achieved <= HBM_PEAK_GBS, (achieved, "required bytes / kernel time exceeds the HBM peak: the byte model is wrong")
         out = {
             "metric": "Mreads/sec matched (150 bp, 20 bp feature, m=%d)" % w["miss"],
-            "value": total_reads / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": total * a.steps / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64 (2-bit packed bases) / u8 qualities", "data": "synthetic",
-            "config": {"workload": a.workload, "reads_per_gpu": n, "read_len": a.read_len, "guides": w["n_guides"],
-                       "guide_len": 20, "miss": w["miss"], "phred": a.phred, "start": 0,
-                       "general_path_reads_per_gpu": info["n_general"], "sharding": f"dp{world}"},
+            "config": {"workload": name, "reads_total": total, "reads_per_gpu": n, "read_len": a.read_len,
+                       "guides": w["n_guides"], "guide_len": 20, "miss": w["miss"], "phred": a.phred, "start": 0,
+                       "general_path_reads_per_gpu": info["n_general"], "sharding": f"dp{world}",
+                       "collective": (f"{a.dist_backend} all_reduce(int64[{w['n_guides'] + 5}]) per step" if use_dist else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": k_ms, "bytes_per_read": B_ALG,
-                         "traffic_source": (f"profiles/r01_{a.workload}_pmc.json: (2*FETCH_SIZE + WRITE_SIZE) KiB of {traffic_kernel}"
-                                            if traffic else None),
+                         "kernel": dominant, "kernel_ms": k_ms, "bytes_per_read": b_req,
+                         "achieved_contract": contract, "frac_contract": contract / HBM_PEAK_GBS,
+                         "bytes_per_read_contract": B_CONTRACT * a.read_len / 150.0,
                          "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "note": ("achieved = 188 algorithmic B/read x reads / kernel time (SURVEY 8(d)); the tile layout lets a "
-                                  "fixed-offset kernel fetch only the rows under the window (traffic = measured HBM bytes), so "
-                                  "achieved may exceed the HBM peak; the anchored workloads (cfg5a/b) fetch every byte")},
+                         "traffic_bytes_per_read": (traffic / n) if traffic else None,
+                         "traffic_detail": traffic_detail,
+                         "note": ("achieved = bytes the kernel must touch per read x reads / HIP-event time of the step's counting "
+                                  "launches on the library's stream (dominant kernel + histogram reduction); achieved_contract uses "
+                                  "SURVEY 8(d)'s 188 B/read, which a fixed-offset kernel does not need to fetch (the tile layout "
+                                  "leaves the rows outside the window untouched) and may therefore exceed the HBM peak")},
+            "verify": verify,
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg, guides, w["miss"])
-        print(json.dumps(out))
+        if world == 1 and not a.no_cpu_baseline:
+            base, one, prefix, fq = cpu_legs(pkg, c, w, a, guides, spec)
+            out["cpu_baseline"], out["cpu_baseline_1core"] = base, one
+            out["verify"]["prefix_vs_oracle"] = prefix
+            assert prefix["equals_oracle"], "device result differs from the oracle on the prefix sample"
+            if not a.no_extras and not w.get("ec"):
+                try:
+                    out["end_to_end"] = end_to_end(pkg, c, fq, prefix["reads"])
+                except Exception as e:              # an optional leg must not take the bench line down
+                    out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+            del fq
+        if world == 1 and not a.no_extras and not a.workload and not a.reads:
+            # the N = 1 leg of the strong-scaling workload the N > 1 runs use, so that the curve has its anchor
+            blk.free(); c.close()
+            try:
+                w4 = dict(WORKLOADS["cfg4_400M_100k_m1"])
+                c4, b4, _, _ = make_job(pkg, w4, a, device, w4["n_reads"], 0)
+                dt4, k4 = timed_steps(c4, b4, 3, 1, None, None, sync)
+                _, s4 = c4.read_counts()
+                out["strong_scaling_n1"] = {"workload": "cfg4_400M_100k_m1", "n_gpus": 1, "steps": 3, "value": w4["n_reads"] * 3 / dt4 / 1e6,
+                                            "unit": "Mreads/s", "ms_per_step": dt4 / 3 * 1e3, "kernel_ms": k4,
+                                            "reads_check": int(s4[0]) == w4["n_reads"] and int(s4[0]) == int(sum(s4[1:]))}
+                b4.free(); c4.close()
+            except Exception as e:
+                out["strong_scaling_n1"] = {"error": f"{type(e).__name__}: {e}"}
+            blk = c = None
+        print(json.dumps(out), flush=True)
+    if blk is not None:
+        blk.free(); c.close()
     if use_dist:
-        # every rank must hold the whole-job result after the last step's all-reduce
-        counts, stats = c.read_counts()
-        chk = torch.tensor([int(stats[0])], device="cuda", dtype=torch.int64)
-        dist.all_reduce(chk, op=dist.ReduceOp.MAX)
-        assert int(chk.item()) == int(stats[0]) == n * world, (int(stats[0]), n * world)
-    blk.free(); c.close()
-    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

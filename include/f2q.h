@@ -98,6 +98,10 @@ typedef struct f2q_block f2q_block;      /* a device-resident block of reads (op
 
 /* ---- lifetime --------------------------------------------------------------------------- */
 int f2q_version(void);
+/* 16 hex digits identifying the sources this binary was compiled from (SHA-256 over csrc/ and this header, computed
+ * by __graft_entry__.build() and passed as -DF2Q_BUILD_ID); "unknown" for a build made any other way.  smoke() and
+ * the GPU tests compare it with the tree they run from, so a stale binary cannot pass for HEAD. */
+const char *f2q_build_id(void);
 /* Replaces the per-file set-up half of reads_counter (fast2q.py:536-558): resolves fixed vs
  * anchored mode and search_iterations, builds the Phred fail thresholds (initializer :1112-1129). */
 int f2q_create(const f2q_params *p, f2q_ctx **out);

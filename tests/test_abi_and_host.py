@@ -31,6 +31,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/f2q.h but not exported"
     assert sorted(binding.EXPORTS) == declared
     assert L.f2q_version() == 1
+    # the binary on disk is the tree's: its baked-in source hash equals the hash of csrc/ + include/f2q.h now
+    assert binding.build_id() == g.source_id()
+
+
+def test_build_sees_every_source_file():
+    import __graft_entry__ as g
+    deps = {os.path.basename(d) for d in g.hip_deps()}
+    on_disk = {f for f in os.listdir(os.path.join(ROOT, "2fast2q_amd", "csrc")) if f.endswith((".h", ".hip"))}
+    assert on_disk <= deps and "f2q.h" in deps
+    # every header the translation unit includes (directly or not) is a dependency
+    for f in on_disk:
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(os.path.join(ROOT, "2fast2q_amd", "csrc", f)).read()):
+            assert os.path.basename(inc) in deps, (f, inc)
 
 
 def test_struct_layout_matches_c(tmp_path):

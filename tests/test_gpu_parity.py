@@ -404,6 +404,43 @@ def test_full_size_config5_cross_paths(P, monkeypatch):
     assert sp2 == sg2 and ecp == ecg
 
 
+def test_full_size_config4_per_gpu(P, monkeypatch):
+    """BASELINE config 4, the per-GPU share (50M x 150 bp reads vs 100k x 20 bp guides, --m 1): the large-library
+    path (feature index per read -> range-partitioned LDS histograms, tables beyond one XCD's L2) against the oracle
+    at 200k reads, against the byte-exact general kernel on a 5M-read slice, and the size-independent identities
+    (5-counter identity, sum of counts, shard-sum invariance) at full size."""
+    lib = P.binding.synth_library(0xF2A5 + 4, 100000, 20)
+    kw = dict(miss=1, phred=30, length=20, start="0")
+    small = dict(seed=0xBEEF, n_reads=200_000, read_len=150)
+    with P.Counter(features=lib, **kw) as c:
+        fq = bytes(c.synth_fastq(**small))
+    orc = O.count_fastq_parallel(fq, 16, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    cs, ss, _, ts = _full(P, monkeypatch, {}, lib, small, **kw)
+    assert ts["general_reads"] == 0 and ss == orc.stats() and cs == orc.counts()
+    sl = dict(small, n_reads=5_000_000)
+    cp, sp, _, _ = _full(P, monkeypatch, {}, lib, sl, **kw)
+    cg, sg, _, tg = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, sl, **kw)
+    assert tg["general_reads"] == 5_000_000 and (cp, sp) == (cg, sg)
+    full = dict(small, n_reads=50_000_000)
+    c4, s4, _, t4 = _full(P, monkeypatch, {}, lib, full, **kw)
+    assert t4["general_reads"] == 0
+    assert s4[0] == 50_000_000 and s4[0] == sum(s4[1:]) and sum(c4) == s4[1] + s4[2]
+    # shard-sum invariance: 8 consecutive shards of the same stream (what 8 ranks would count) add up to the whole
+    with P.Counter(features=lib, **kw) as c:
+        for r in range(8):
+            b = c.synth_create(first_read=r * 6_250_000, **dict(full, n_reads=6_250_000))
+            c.count_resident(b)
+            b.free()
+        c8, s8 = c.read_counts()
+    assert list(s8) == s4 and list(c8) == c4
+
+
+def test_library_is_built_from_this_tree(P):
+    """the .so the tests load carries the hash of the sources in this tree (no stale binary)"""
+    import __graft_entry__ as g
+    assert P.binding.build_id() == g.source_id()
+
+
 @pytest.mark.parametrize("start,length,rl", [(0, 20, 150), (7, 29, 60), (3, 12, 14), (10, 8, 9), (0, 0, 30), (5, 30, 80)])
 def test_extract_count_fixed_window_gpu(P, start, length, rl):
     guides = synth.make_library(60, max(8, min(length, 20)), 777)
