@@ -301,6 +301,163 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     }
 }
 
+// ---- fast path v3: the library in LDS ------------------------------------------------------------------
+// Fixed-offset Counter mode for uniform libraries of 14..21-base features searched with --m <= 1 (the reference's
+// default, and BASELINE configs 2 and 3): the tile walk of k_count_fixed4, but every lookup -- exact hit and the
+// unique-feature-at-distance-1 search -- is answered from two cuckoo tables of 32-bit tags held in the workgroup's LDS
+// (f2q_device.h, "LDS tables"): four 8-byte LDS reads per read, no table traffic to L2 at all, no ring, no second pass.
+// One 1024-thread workgroup per CU owns the whole 160 KiB: 2 x 64 KiB of tags + a 32 KiB histogram of u16 counters
+// (two per word, indexed by table-0 slot).  A counter that reaches 0x8000 moves 0x8000 counts to the global vector
+// (lt_count), so no count is lost however skewed the library's popularity is.  The rows of the wave's next tile are
+// requested before the current tile is decided (one tile in flight per wave hides the HBM latency).
+#define F2Q_LT_THREADS 1024
+#define F2Q_LT_WAVES (F2Q_LT_THREADS / 64)
+
+__device__ __forceinline__ U2 lds_u2(const uint32_t *p)
+{
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    const v2 v = *reinterpret_cast<const v2 *>(p);              // ds_read_b64
+    return U2{v.x, v.y};
+}
+
+__device__ __forceinline__ void lt_count(uint32_t *cnt, uint32_t slot, const Accum &acc, const LtDesc &lt)
+{
+    const uint32_t sh = (slot & 1u) << 4;
+    const uint32_t old = atomicAdd(&cnt[slot >> 1], 1u << sh);
+    // exactly one adder sees the counter pass 0x7FFF -> 0x8000; it takes 0x8000 out again (no borrow: the counter only
+    // grows until then, and by far less than another 0x8000) and credits the feature's global counter
+    if (((old >> sh) & 0xFFFFu) == 0x7FFFu) {
+        atomicSub(&cnt[slot >> 1], 0x8000u << sh);
+        acc_add(&acc.counts[gp(lt.feat_of)[slot]], 0x8000ull);
+    }
+}
+
+template <int NQ, int NB, bool NEAR>
+__global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDev *__restrict__ runp,
+                                                                     const LibDev *__restrict__ libp, PackedBlock pb,
+                                                                     Accum acc)
+{
+    extern __shared__ uint32_t lt_smem[];
+    constexpr uint32_t NT = NEAR ? 2u : 1u;
+    uint32_t *tg = lt_smem;                                     // [NT][F2Q_LT_SLOTS] tags
+    uint32_t *cnt = lt_smem + NT * F2Q_LT_SLOTS;                // [F2Q_LT_BUCKETS] two u16 counters per word
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const LtDesc lt = lib.lt;
+    const uint32_t nf = lib.n_features;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(lt.tags);
+        v4 *dst = reinterpret_cast<v4 *>(tg);
+        for (uint32_t i = tid; i < NT * F2Q_LT_SLOTS / 4u; i += F2Q_LT_THREADS) dst[i] = src[i];
+        for (uint32_t i = tid; i < F2Q_LT_BUCKETS; i += F2Q_LT_THREADS) cnt[i] = 0;
+    }
+    __syncthreads();
+    const FixedGeom g = fixed_geom(run);
+    const int need = g.st + g.L;
+    const bool do_near = NEAR && run.miss > 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+    constexpr int QR = NQ ? NQ : F2Q_MAXQROWS, BR = NB ? NB : F2Q_MAXBROWS;
+    constexpr bool PIPE = NQ != 0;                              // run-time geometry: 12 rows, too many to keep two tiles of
+
+    U4 nbrow[BR], nqrow[QR]; uint32_t nlen01 = 0, nlen23 = 0;
+    auto request_tile = [&](uint32_t t) {
+        const auto qp = gp(pb.qual) + (uint64_t)t * pb.wq * F2Q_TILE + 4u * lane;
+        const auto bp = gp(pb.bases) + (uint64_t)t * pb.wb * F2Q_TILE + 4u * lane;
+#pragma unroll
+        for (int r = 0; r < BR; r++) {
+            const uint32_t row = (uint32_t)g.bw0 + (uint32_t)(NB ? r : (r < g.nb ? r : g.nb - 1));   // the host checked: rows exist
+            nbrow[r] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
+        }
+#pragma unroll
+        for (int r = 0; r < QR; r++) {
+            const uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : g.nq - 1));
+            nqrow[r] = ld_u4<true>(qp + (uint64_t)row * F2Q_TILE);
+        }
+        if (pb.len) {
+            typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+            const v2 lv = __builtin_nontemporal_load((const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)t * F2Q_TILE + 4u * lane));
+            nlen01 = lv.x; nlen23 = lv.y;
+        }
+    };
+    const uint32_t stride = gridDim.x * F2Q_LT_WAVES;
+    uint32_t tile = blockIdx.x * F2Q_LT_WAVES + wave;
+    if (PIPE && tile < pb.n_tiles) request_tile(tile);
+    for (; tile < pb.n_tiles; tile += stride) {
+        if (!PIPE) request_tile(tile);
+        U4 brow[BR], qrow[QR];
+#pragma unroll
+        for (int r = 0; r < BR; r++) brow[r] = nbrow[r];
+#pragma unroll
+        for (int r = 0; r < QR; r++) qrow[r] = nqrow[r];
+        const uint32_t len01 = nlen01, len23 = nlen23;
+        if (PIPE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + stride < pb.n_tiles) request_tile(tile + stride);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t bad[4] = {0, 0, 0, 0};
+        if (g.add_hi) {
+#pragma unroll
+            for (int r = 0; r < QR; r++)
+                if (NQ || r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+            int res;
+            if (l == F2Q_LEN_SKIP) res = R_SKIP;
+            // a read that ends inside the window gives a shorter key (:354); every feature is L long, so it can equal
+            // or approach none (:683); its bytes past the end are stored as 0 and never fail the Phred test
+            else if ((int)(l & 0x7FFFu) < need) res = bad[j] ? R_QFAIL : R_NONALIGNED;
+            else if (bad[j]) res = R_QFAIL;
+            else {
+                const uint64_t key = fixed4_key(g, brow, j);
+                uint32_t forced = 0;
+                if (l & F2Q_LEN_FLAG) forced = fixed4_flags(g, qrow, j);      // non-ACGT symbols in the window (rare)
+                const LtProbe q = lt_probe(lt, key);
+                U2 e[4];
+#pragma unroll
+                for (int k = 0; k < (NEAR ? 4 : 2); k++) e[k] = lds_u2(tg + (uint32_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q.b[k]);
+                if (!NEAR) { e[2] = U2{F2Q_LT_EMPTY, F2Q_LT_EMPTY}; e[3] = e[2]; }
+                res = R_NONALIGNED;
+                if (forced == 0u) {
+                    const int ex = lt_exact(lt, q, e[0], e[1]);
+                    if (ex >= 0) { res = R_PERFECT; lt_count(cnt, (uint32_t)ex, acc, lt); }
+                    else if (do_near) {
+                        uint32_t hit;
+                        if (lt_near1(lt, q, e, 0u, hit) == 1u) {
+                            const uint32_t slot = (hit >> 16) ? (uint32_t)gp(lt.xref)[hit & 0xFFFFu] : hit;
+                            res = R_IMPERFECT; lt_count(cnt, slot, acc, lt);
+                        }
+                    }
+                } else if (do_near && __popc(forced) <= run.miss) {
+                    uint32_t hit;
+                    if (lt_near1(lt, q, e, forced, hit) == 1u) {
+                        const uint32_t slot = (hit >> 16) ? (uint32_t)gp(lt.xref)[hit & 0xFFFFu] : hit;
+                        res = R_IMPERFECT; lt_count(cnt, slot, acc, lt);
+                    }
+                }
+            }
+            st0 += (res != R_SKIP); st1 += (res == R_PERFECT); st2 += (res == R_IMPERFECT);
+            st3 += (res == R_NONALIGNED); st4 += (res == R_QFAIL);
+        }
+    }
+    __syncthreads();
+    // the histogram leaves as one slab row in feature order; k_reduce_slabs sums the rows
+    {
+        auto row = gpw(acc.slab) + (uint64_t)blockIdx.x * nf;
+        for (uint32_t i = tid; i < nf; i += F2Q_LT_THREADS) {
+            const uint32_t s = gp(lt.slot_of)[i];
+            row[i] = (cnt[s >> 1] >> ((s & 1u) << 4)) & 0xFFFFu;
+        }
+    }
+    __syncthreads();
+    unsigned long long stv[5] = {st0, st1, st2, st3, st4};
+    flush_stats(acc, stv, reinterpret_cast<unsigned long long *>(lt_smem), acc.stat_slab + (uint64_t)blockIdx.x * 8u);   // the tables are done with
+}
+
 // Extract+Count with a fixed window (--mo EC --st/--l): same tile walk and Phred test as k_count_fixed4, but every
 // passing window (clipped to the read, possibly empty) is a key of the single-word device table -- no library.
 __global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev *__restrict__ runp, EcDev ec, PackedBlock pb,

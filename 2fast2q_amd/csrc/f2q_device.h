@@ -79,10 +79,27 @@ struct PackedGroup {
     PackedPiece piece[F2Q_MAX_PIECES];
 };
 
+// "LDS tables" of a uniform library of 14..21-base features searched with --m <= 1 (see the section further down):
+// two cuckoo tables of 32-bit tags small enough for a workgroup to keep in LDS next to its histogram.
+#define F2Q_LT_BBITS 13u
+#define F2Q_LT_BUCKETS (1u << F2Q_LT_BBITS)       // per table; a bucket is two slots (one 8-byte LDS read)
+#define F2Q_LT_SLOTS (2u * F2Q_LT_BUCKETS)
+#define F2Q_LT_EMPTY 0xFFFFFFFFu
+struct LtDesc {
+    uint32_t ok;                       // 1: tables built for this library
+    uint32_t len;                      // feature length L
+    uint32_t hb0, hb1;                 // bits of half 0 (bases [0, L/2)) and half 1 (the rest)
+    const uint32_t *tags;              // [2][F2Q_LT_SLOTS]: table t is bucketed by half t and stores the other half in its tags
+    const uint16_t *xref;              // [F2Q_LT_SLOTS] table-1 slot -> table-0 slot of the same feature
+    const uint16_t *slot_of;           // [n_features] table-0 slot of a feature = its counter in the LDS histogram
+    const uint32_t *feat_of;           // [F2Q_LT_SLOTS] feature of a table-0 slot (unused slots: 0)
+};
+
 struct LibDev {
     uint32_t n_features, n_irregular;
     const uint64_t *ptab;              // packed slots (KEY_EMPTY = free)
     PackedGroup pk;
+    LtDesc lt;
     const uint64_t *tab_keys;          // open-addressing slots: 2-bit feature key or KEY_EMPTY
     const uint32_t *tab_idx;           // feature index of the slot
     const uint8_t *feat_bytes;         // all features, raw (upper-case) bytes
@@ -874,6 +891,126 @@ F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key
     return R_NONALIGNED;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS tables: the whole library inside the workgroup's LDS (north star: "the feature table tiled into LDS").
+// Applies to Counter-mode runs whose features all have the window length L, 14 <= L <= 21, ACGT only, searched with
+// --m <= 1, when the cuckoo build below succeeds (up to ~13 k features).  A key is cut into half 0 (bases [0, L/2))
+// and half 1 (the rest).  Table t holds every feature once, in one of the two buckets that half t alone selects
+// (two bijective scrambles of the half; a bucket = 2 slots = one ds_read_b64), as a 32-bit tag
+//     [choice c : 1][0...][half t scrambled by choice c, bits above the bucket index][other half, unscrambled]
+// so bucket + tag determine the key, and an empty slot (all ones) equals no tag.  One read costs four 8-byte LDS
+// loads and no memory access outside the streamed tile rows:
+//   exact hit    (fast2q.py:365-367)   an entry of table 0 with the same half 0 and the same half 1
+//   1 mismatch   (:692-750, --m 1)     a feature at distance exactly 1 agrees with the query on exactly one half, so
+//                                      it sits in the query's buckets of exactly one table: the entries with the same
+//                                      half t whose other half differs in one base are ALL the candidates; assign iff
+//                                      there is exactly one (unique nearest, distance 1)
+// A flagged (non-ACGT) query base is a forced mismatch: with one of them the candidates are the entries of the table
+// bucketed by the clean half whose other half agrees everywhere else.  Counts go to a u16 histogram indexed by the
+// table-0 slot (lt_count); table-1 hits find that slot through xref.
+// ---------------------------------------------------------------------------------------------
+F2Q_HD uint32_t lt_mul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__umul24(a, b);          // both operands < 2^24: one full-rate v_mul_u32_u24
+#else
+    return a * b;
+#endif
+}
+// bijective scramble c of a half value (bits wide, 13 < bits <= 22): multiply by an odd constant modulo 2^bits, then
+// fold the high bits onto the low ones (both steps are invertible); bucket = low 13 bits, the rest goes into the tag
+F2Q_HD uint32_t lt_perm(uint32_t h, uint32_t bits, int c)
+{
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t v = lt_mul24(h, c ? 0x9E3779u : 0x85EBCBu) & mask;
+    v ^= v >> (bits - 10u);
+    v = lt_mul24(v, c ? 0x2C1B3Du : 0x297A2Du) & mask;
+    v ^= v >> (bits - F2Q_LT_BBITS + 3u);
+    return v;
+}
+// choice c of half value h of table t: bucket and what (entry >> ob) must equal for "same half" (ob = bits of the other half)
+F2Q_HD void lt_hash(uint32_t h, uint32_t bits, uint32_t ob, int c, uint32_t &bucket, uint32_t &cmp)
+{
+    const uint32_t v = lt_perm(h, bits, c);
+    bucket = v & (F2Q_LT_BUCKETS - 1u);
+    cmp = ((uint32_t)c << (31u - ob)) | (v >> F2Q_LT_BBITS);
+}
+F2Q_HD uint32_t lt_tag(uint32_t cmp, uint32_t other, uint32_t ob) { return (cmp << ob) | other; }
+
+F2Q_HD uint32_t ham2_32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
+#else
+    return (uint32_t)__builtin_popcount((x | (x >> 1)) & 0x55555555u);
+#endif
+}
+F2Q_HD uint32_t spread16(uint32_t v)          // bit i -> bit 2i, i < 16
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+struct U2 { uint32_t x, y; };
+// the four bucket addresses of a key (table-0 choices 0/1, table-1 choices 0/1) and their "same half" comparands
+struct LtProbe { uint32_t b[4], cmp[4], h0, h1; };
+F2Q_HD LtProbe lt_probe(const LtDesc &lt, uint64_t key)
+{
+    LtProbe q;
+    q.h0 = (uint32_t)key & ((1u << lt.hb0) - 1u);
+    q.h1 = (uint32_t)(key >> lt.hb0);
+    lt_hash(q.h0, lt.hb0, lt.hb1, 0, q.b[0], q.cmp[0]);
+    lt_hash(q.h0, lt.hb0, lt.hb1, 1, q.b[1], q.cmp[1]);
+    lt_hash(q.h1, lt.hb1, lt.hb0, 0, q.b[2], q.cmp[2]);
+    lt_hash(q.h1, lt.hb1, lt.hb0, 1, q.b[3], q.cmp[3]);
+    return q;
+}
+// exact hit among the two table-0 buckets: slot or -1
+F2Q_HD int lt_exact(const LtDesc &lt, const LtProbe &q, const U2 &e0, const U2 &e1)
+{
+    const uint32_t w0 = lt_tag(q.cmp[0], q.h1, lt.hb1), w1 = lt_tag(q.cmp[1], q.h1, lt.hb1);
+    if (e0.x == w0) return (int)(2u * q.b[0]);
+    if (e0.y == w0) return (int)(2u * q.b[0] + 1u);
+    if (e1.x == w1) return (int)(2u * q.b[1]);
+    if (e1.y == w1) return (int)(2u * q.b[1] + 1u);
+    return -1;
+}
+// candidates at distance exactly 1 among the four buckets e[0..3] (see the section comment).  forced: one bit per base
+// of the window that mismatches every feature.  Returns the number of candidates; hit = table (0/1) << 16 | slot of one.
+F2Q_HD uint32_t lt_near1(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], uint32_t forced, uint32_t &hit)
+{
+    const uint32_t l0 = lt.hb0 >> 1;
+    const uint32_t f0 = forced & ((1u << l0) - 1u), f1 = forced >> l0;
+    uint32_t nf = 0, keep0 = ~0u, keep1 = ~0u;
+    if (forced) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        nf = (uint32_t)__popc(forced);
+#else
+        nf = (uint32_t)__builtin_popcount(forced);
+#endif
+        const uint32_t s0 = spread16(f0), s1 = spread16(f1);
+        keep0 = ~(s0 | (s0 << 1)); keep1 = ~(s1 | (s1 << 1));
+    }
+    uint32_t n = 0;
+    hit = 0;
+    const uint32_t m0 = (1u << lt.hb0) - 1u, m1 = (1u << lt.hb1) - 1u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool t1 = k >= 2;                       // table 1: same half 1, other half = half 0
+        if (t1 ? (f1 != 0u) : (f0 != 0u)) continue;   // a flagged base in the bucketing half: it can agree with nothing
+        const uint32_t ob = t1 ? lt.hb0 : lt.hb1, om = t1 ? m0 : m1, oq = t1 ? q.h0 : q.h1, keep = t1 ? keep0 : keep1;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t w = i ? e[k].y : e[k].x;
+            const bool same = (w >> ob) == q.cmp[k];
+            const uint32_t d = ham2_32(((w ^ oq) & om) & keep) + nf;
+            if (same && d == 1u) { n++; hit = ((uint32_t)t1 << 16) | (2u * q.b[k] + (uint32_t)i); }
+        }
+    }
+    return n;
+}
 // ---------------------------------------------------------------------------------------------
 // fast path, anchored (--us / --ds): one lane = one read held as two bit-planes.
 // Planar tile layout (anchored runs): base rows 0..NW-1 hold the LOW bit of 32 bases per word,

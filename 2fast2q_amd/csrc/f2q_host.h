@@ -24,6 +24,10 @@ struct HostIndex {
     std::vector<uint64_t> key2;          // 2-bit key per feature (0 for irregular ones)
     std::vector<uint64_t> ptab;          // packed slots of the run's feature length (v2 fast kernel)
     PackedGroup pk;
+    // LDS tables (f2q_device.h: LtDesc); lt.ok == 0: not applicable / the cuckoo build failed
+    LtDesc lt{};
+    std::vector<uint32_t> lt_tags, lt_feat_of;
+    std::vector<uint16_t> lt_xref, lt_slot_of;
     LenGroup grp[F2Q_REG_MAXLEN + 1];
     uint32_t n_features = 0, n_irregular = 0;
 };
@@ -94,6 +98,66 @@ inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int le
     }
 }
 
+// LDS tables for a library whose features all have the window length (f2q_device.h, "LDS tables").  Cuckoo
+// insertion with two buckets of two slots per key and table: an occupied pair of buckets evicts one resident
+// (round robin over the four slots), which moves to its other bucket, up to a bounded number of moves.
+inline void build_lt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, int miss)
+{
+    memset(&ix.lt, 0, sizeof ix.lt);
+    ix.lt_tags.assign(1, F2Q_LT_EMPTY); ix.lt_feat_of.assign(1, 0); ix.lt_xref.assign(1, 0); ix.lt_slot_of.assign(1, 0);
+    if (len < 14 || len > 21 || miss > 1 || ids.empty() || ids.size() != ix.n_features) return;
+    if (ids.size() > (size_t)(F2Q_LT_SLOTS * 0.87)) return;
+    LtDesc lt{};
+    lt.len = (uint32_t)len; lt.hb0 = 2u * (uint32_t)(len / 2); lt.hb1 = 2u * (uint32_t)len - lt.hb0;
+    std::vector<uint32_t> tags(2 * (size_t)F2Q_LT_SLOTS, F2Q_LT_EMPTY);
+    std::vector<uint32_t> owner(2 * (size_t)F2Q_LT_SLOTS, ~0u);         // feature stored in a slot
+    for (int t = 0; t < 2; t++) {
+        uint32_t *tg = tags.data() + (size_t)t * F2Q_LT_SLOTS, *ow = owner.data() + (size_t)t * F2Q_LT_SLOTS;
+        const uint32_t hb = t ? lt.hb1 : lt.hb0, ob = t ? lt.hb0 : lt.hb1;
+        auto halves = [&](uint32_t f, uint32_t &h, uint32_t &o) {
+            const uint64_t k = ix.key2[f];
+            const uint32_t h0 = (uint32_t)k & ((1u << lt.hb0) - 1u), h1 = (uint32_t)(k >> lt.hb0);
+            h = t ? h1 : h0; o = t ? h0 : h1;
+        };
+        uint64_t rs = 0x9E3779B97F4A7C15ull + (uint64_t)t;       // fixed seed: the tables are a pure function of the library
+        for (uint32_t f0 : ids) {
+            uint32_t f = f0, from = ~0u;                 // slot the feature in hand was evicted from
+            bool placed = false;
+            for (int moves = 0; moves < 20000 && !placed; moves++) {
+                uint32_t h, o; halves(f, h, o);
+                uint32_t b[2], cmp[2];
+                lt_hash(h, hb, ob, 0, b[0], cmp[0]); lt_hash(h, hb, ob, 1, b[1], cmp[1]);
+                for (int c = 0; c < 2 && !placed; c++)
+                    for (int i = 0; i < 2 && !placed; i++) {
+                        const uint32_t s = 2u * b[c] + (uint32_t)i;
+                        if (tg[s] == F2Q_LT_EMPTY) { tg[s] = lt_tag(cmp[c], o, ob); ow[s] = f; placed = true; }
+                    }
+                if (placed) break;
+                // random walk: evict a random resident of the four slots, not the one just vacated for this feature
+                uint32_t s; int c;
+                for (int tries = 0;; tries++) {
+                    rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+                    c = (int)((rs >> 33) & 1u);
+                    s = 2u * b[c] + (uint32_t)((rs >> 34) & 1u);
+                    if (s != from || tries > 8) break;
+                }
+                const uint32_t g = ow[s];
+                tg[s] = lt_tag(cmp[c], o, ob); ow[s] = f;
+                from = s; f = g;
+            }
+            if (!placed) return;                       // no LDS tables for this library (lt.ok stays 0)
+        }
+    }
+    ix.lt_slot_of.assign(ix.n_features, 0); ix.lt_feat_of.assign(F2Q_LT_SLOTS, 0); ix.lt_xref.assign(F2Q_LT_SLOTS, 0);
+    for (uint32_t s = 0; s < F2Q_LT_SLOTS; s++)
+        if (owner[s] != ~0u) { ix.lt_slot_of[owner[s]] = (uint16_t)s; ix.lt_feat_of[s] = owner[s]; }
+    for (uint32_t s = 0; s < F2Q_LT_SLOTS; s++)
+        if (owner[F2Q_LT_SLOTS + s] != ~0u) ix.lt_xref[s] = ix.lt_slot_of[owner[F2Q_LT_SLOTS + s]];
+    ix.lt_tags.swap(tags);
+    lt.ok = 1;
+    ix.lt = lt;
+}
+
 inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss, int packed_len = 0)
 {
     ix = HostIndex();
@@ -149,6 +213,7 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
     }
     build_packed(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(),
                  packed_len, miss);
+    build_lt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss);
     ix.n_irregular = (uint32_t)ix.irr_ids.size();
     if (ix.irr_ids.empty()) ix.irr_ids.push_back(0);     // keep the device array non-empty
 }

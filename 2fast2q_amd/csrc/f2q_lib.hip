@@ -79,6 +79,7 @@ struct f2q_ctx {
     bool host_pack = false;               // F2Q_HOST_PACK=1: frame/classify/pack on the host (the round-1 first path; A/B runs)
     bool force_general = false;           // F2Q_FORCE_GENERAL=1: every read through the byte-exact general kernel (cross-checks)
     bool force_v1 = false;                // F2Q_FORCE_V1=1: keep the one-read-per-lane kernel (A/B runs)
+    bool no_lt = false;                   // F2Q_NO_LT=1: never the LDS-table kernel (A/B runs, cross-checks)
     // device memory freed by blocks / scratch is kept (idle, after a stream sync) for the next piece of the same
     // size class: a streamed file costs ~20 allocations per piece otherwise
     std::multimap<size_t, void *> dev_idle;
@@ -218,6 +219,14 @@ static int upload_lib(f2q_ctx *c)
     if ((rc = dev_upload(c, c->ix.key2.data(), c->ix.key2.size(), &gk, c->lib_allocs))) return rc;
     if ((rc = dev_upload(c, c->ix.ptab.data(), c->ix.ptab.size(), &pt, c->lib_allocs))) return rc;
     L.ptab = pt;
+    {
+        uint32_t *lt_tags, *lt_feat; uint16_t *lt_xref, *lt_slot;
+        if ((rc = dev_upload(c, c->ix.lt_tags.data(), c->ix.lt_tags.size(), &lt_tags, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.lt_feat_of.data(), c->ix.lt_feat_of.size(), &lt_feat, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.lt_xref.data(), c->ix.lt_xref.size(), &lt_xref, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.lt_slot_of.data(), c->ix.lt_slot_of.size(), &lt_slot, c->lib_allocs))) return rc;
+        L.lt = c->ix.lt; L.lt.tags = lt_tags; L.lt.feat_of = lt_feat; L.lt.xref = lt_xref; L.lt.slot_of = lt_slot;
+    }
     L.tab_keys = tk; L.tab_idx = ti; L.feat_bytes = fb; L.feat_off = fo; L.irr_ids = ir;
     c->guide_keys_d = gk;
     LibDev *ld;
@@ -256,6 +265,7 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     { const char *tr = getenv("F2Q_TRACE"); c->trace = tr && tr[0] == '1'; }
     { const char *dc = getenv("F2Q_DEV_CACHE_MB"); if (dc && atol(dc) >= 0) c->dev_idle_cap = (size_t)atol(dc) << 20; }
     { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_NO_LT"); c->no_lt = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_HOST_PACK"); c->host_pack = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_FORCE_GENERAL"); c->force_general = fv && fv[0] == '1'; }
     int rc = setup_run(c);
@@ -510,7 +520,36 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
         const bool v2 = !c->force_v1 && c->lib_h.pk.len == (uint32_t)c->run_h.length && c->lib_h.pk.len > 0 &&
                         c->lib_h.n_irregular == 0;
-        if (v2) {
+        const FixedGeom fgeo = fixed_geom(c->run_h);
+        // the library in LDS: uniform 14..21-base library, --m <= 1, and tiles that hold every row under the window
+        const bool use_lt = v2 && lds && !c->no_lt && c->lib_h.lt.ok && c->lib_h.lt.len == (uint32_t)c->run_h.length &&
+                            c->run_h.miss <= 1 && (uint32_t)(fgeo.qw0 + fgeo.nq) <= pb.wq && (uint32_t)(fgeo.bw0 + fgeo.nb) <= pb.wb;
+        if (use_lt) {
+            const uint32_t wgs = (pb.n_tiles + F2Q_LT_WAVES - 1) / F2Q_LT_WAVES;
+            const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu);
+            const bool near = c->run_h.miss > 0;
+            const size_t shmem = ((near ? 2u : 1u) * (size_t)F2Q_LT_SLOTS + F2Q_LT_BUCKETS) * 4;
+            const bool spec52 = !c->force_generic && fgeo.nq == 5 && fgeo.nb == 2 && c->run_h.thr >= 33;
+            auto kern = near ? (spec52 ? k_count_fixed4_lds<5, 2, true> : k_count_fixed4_lds<0, 0, true>)
+                             : (spec52 ? k_count_fixed4_lds<5, 2, false> : k_count_fixed4_lds<0, 0, false>);
+            const uint32_t nf_ = c->lib_h.n_features;
+            const size_t need = (size_t)grid * nf_;
+            if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
+                if (c->slab_d) (void)hipFree(c->slab_d);
+                if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
+                c->slab_d = nullptr; c->slab_n = 0; c->stat_slab_d = nullptr; c->stat_slab_n = 0;
+                HIPC(c, hipMalloc((void **)&c->slab_d, std::max<size_t>(need, 1) * sizeof(uint32_t)));
+                HIPC(c, hipMalloc((void **)&c->stat_slab_d, (size_t)grid * 8 * sizeof(unsigned long long)));
+                c->slab_n = need; c->stat_slab_n = grid;
+            }
+            acc.slab = c->slab_d; acc.stat_slab = c->stat_slab_d;
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_LT_THREADS), shmem, c->stream, c->run_d, c->lib_d, pb, acc);
+            HIPC(c, hipGetLastError());
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((nf_ + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
+                               c->slab_d, grid, nf_, acc.counts, c->stat_slab_d, grid, acc.stats);
+            launches++;
+        } else if (v2) {
             const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
             const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 4);

@@ -23,7 +23,8 @@ struct Emu {
     std::vector<unsigned long long> acc;      // counts + 5 stats
     EcDev ec; std::vector<unsigned long long> slots, ent_off, ent_count, ent_first, ctr, k64s, k64c, k64f; std::vector<uint32_t> ent_len, arena;
     uint64_t reads_seen = 0, fast = 0, general = 0, v2_reads = 0, anchor_reads = 0;
-    int use_v2 = 1;
+    int use_v2 = 1, use_lt = 1;
+    uint64_t lt_reads = 0;
     std::string err;
 };
 
@@ -34,6 +35,8 @@ static void bind_lib(Emu *e)
     L.tab_keys = e->ix.tab_keys.data(); L.tab_idx = e->ix.tab_idx.data();
     L.ptab = e->ix.ptab.data(); L.pk = e->ix.pk;
     L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
+    L.lt = e->ix.lt; L.lt.tags = e->ix.lt_tags.data(); L.lt.xref = e->ix.lt_xref.data(); L.lt.slot_of = e->ix.lt_slot_of.data();
+    L.lt.feat_of = e->ix.lt_feat_of.data();
     memcpy(L.grp, e->ix.grp, sizeof L.grp);
     e->acc.assign(e->ix.n_features + 5, 0);
 }
@@ -255,6 +258,26 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                         res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
                     else if ((int)(l & 0x7FFFu) < need) res = bad[j] ? R_QFAIL : R_NONALIGNED;   // clipped window, uniform library
                     else if (bad[j]) res = R_QFAIL;
+                    else if (e->use_lt && e->lib.lt.ok && rows_ok) {
+                        // k_count_fixed4_lds: the LDS tables decide (exact hit, else the unique feature at distance 1)
+                        const LtDesc &lt = e->lib.lt;
+                        const uint64_t key = fixed4_key(g, b, j);
+                        const uint32_t forced = (l & F2Q_LEN_FLAG) ? fixed4_flags(g, qr, j) : 0u;
+                        const LtProbe q = lt_probe(lt, key);
+                        U2 en[4];
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t *tb = lt.tags + (size_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q.b[k];
+                            en[k] = U2{tb[0], tb[1]};
+                        }
+                        uint32_t slot = 0, hit = 0;
+                        const int ex = forced ? -1 : lt_exact(lt, q, en[0], en[1]);
+                        if (ex >= 0) { res = R_PERFECT; slot = (uint32_t)ex; }
+                        else if (e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss) res = R_NONALIGNED;
+                        else if (lt_near1(lt, q, en, forced, hit) == 1u) { res = R_IMPERFECT; slot = (hit >> 16) ? lt.xref[hit & 0xFFFFu] : (hit & 0xFFFFu); }
+                        else res = R_NONALIGNED;
+                        idx = lt.feat_of[slot];
+                        e->lt_reads++;
+                    }
                     else {
                         uint64_t key = fixed4_key(g, b, j);
                         uint32_t forced = (l & F2Q_LEN_FLAG) ? fixed4_flags(g, qr, j) : 0u;
@@ -302,6 +325,9 @@ void emu_read_counts(void *h, int64_t *counts, int64_t *stats, uint64_t *fast, u
 
 void emu_set_read_base(void *h, uint64_t b) { ((Emu *)h)->reads_seen = b; }
 void emu_use_v2(void *h, int on) { ((Emu *)h)->use_v2 = on; }
+void emu_use_lt(void *h, int on) { ((Emu *)h)->use_lt = on; }
+uint64_t emu_lt_reads(void *h) { return ((Emu *)h)->lt_reads; }
+int emu_lt_ok(void *h) { return (int)((Emu *)h)->ix.lt.ok; }
 uint64_t emu_v2_reads(void *h) { return ((Emu *)h)->v2_reads; }
 uint64_t emu_anchor_reads(void *h) { return ((Emu *)h)->anchor_reads; }
 // entries: first the byte-string table, then the occupied slots of the single-word table

@@ -43,6 +43,10 @@ def lib():
         L.emu_use_v2.argtypes = [vp, C.c_int]
         L.emu_v2_reads.restype = C.c_uint64
         L.emu_v2_reads.argtypes = [vp]
+        L.emu_use_lt.argtypes = [vp, C.c_int]
+        L.emu_lt_reads.restype = C.c_uint64
+        L.emu_lt_reads.argtypes = [vp]
+        L.emu_lt_ok.argtypes = [vp]
         L.emu_anchor_reads.restype = C.c_uint64
         L.emu_anchor_reads.argtypes = [vp]
         L.emu_ec_n.restype = C.c_uint64
@@ -73,12 +77,13 @@ def read_file(path, piece=1 << 16, threads=0, out_cap=1 << 26):
 
 
 class Emu:
-    def __init__(self, features=None, v2=True, **params):
+    def __init__(self, features=None, v2=True, lt=True, **params):
         self._p, self._keep = binding.make_params(**params)
         self._h = C.c_void_p(lib().emu_create(C.byref(self._p)))
         if not self._h:
             raise ValueError("emu_create failed")
         lib().emu_use_v2(self._h, 1 if v2 else 0)
+        lib().emu_use_lt(self._h, 1 if lt else 0)
         self.n = 0
         if features is not None:
             enc = [s.encode("latin-1") for s in features]
@@ -93,6 +98,14 @@ class Emu:
 
     def v2_reads(self):
         return lib().emu_v2_reads(self._h)
+
+    def lt_reads(self):
+        """reads decided by the LDS-table logic (k_count_fixed4_lds)"""
+        return lib().emu_lt_reads(self._h)
+
+    def lt_ok(self):
+        """the cuckoo build of the LDS tables succeeded for the library"""
+        return bool(lib().emu_lt_ok(self._h))
 
     def anchor_reads(self):
         return lib().emu_anchor_reads(self._h)

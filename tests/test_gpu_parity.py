@@ -369,11 +369,12 @@ def test_full_size_config3_cross_paths(P, monkeypatch):
     lib = P.binding.synth_library(0xF2A5 + 3, 10000, 20)
     spec = dict(seed=0xBEEF, n_reads=50_000_000, read_len=150)
     kw = dict(miss=1, phred=30, length=20, start="0")
-    c2, s2, _, t2 = _full(P, monkeypatch, {}, lib, spec, **kw)
+    c2, s2, _, t2 = _full(P, monkeypatch, {}, lib, spec, **kw)                       # the library-in-LDS kernel
     c1, s1, _, _ = _full(P, monkeypatch, {"F2Q_FORCE_V1": "1"}, lib, spec, **kw)
+    c3, s3, _, _ = _full(P, monkeypatch, {"F2Q_NO_LT": "1"}, lib, spec, **kw)       # the pigeonhole kernel on L2 tables
     assert s2[0] == 50_000_000 and s2[0] == sum(s2[1:]) and sum(c2) == s2[1] + s2[2]
     assert t2["general_reads"] == 0
-    assert (c1, s1) == (c2, s2)
+    assert (c1, s1) == (c2, s2) and (c3, s3) == (c2, s2)
     spec_q = dict(spec, n_reads=12_500_000)                       # a quarter through the general kernel (byte-wise, slow)
     cg, sg, _, tg = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, spec_q, **kw)
     cq, sq, _, _ = _full(P, monkeypatch, {}, lib, spec_q, **kw)
@@ -433,6 +434,46 @@ def test_full_size_config4_per_gpu(P, monkeypatch):
             b.free()
         c8, s8 = c.read_counts()
     assert list(s8) == s4 and list(c8) == c4
+
+
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("glen,n_guides,start,rl", [(20, 10000, 0, 150), (20, 13000, 3, 60), (14, 800, 5, 40), (21, 6000, 2, 75), (17, 2000, 9, 150)])
+def test_lds_table_kernel_vs_oracle(P, monkeypatch, miss, glen, n_guides, start, rl):
+    """k_count_fixed4_lds (library in LDS: cuckoo tag tables + u16 histogram) against the oracle and against the
+    pigeonhole kernel (F2Q_NO_LT=1) on dense mutations, N symbols, near-duplicate features and clipped reads"""
+    guides = P.binding.synth_library(31 * glen + n_guides, n_guides, glen)
+    twins = []
+    for i, g in enumerate(guides[:300]):
+        p = (i * 7) % glen
+        twins.append(g[:p] + "ACGT"[("ACGT".index(g[p]) + 1 + i % 3) % 4] + g[p + 1:])
+    lib = list(dict.fromkeys(guides + twins))
+    kw = dict(miss=miss, length=glen, start=str(start))
+    spec = dict(seed=glen + miss, n_reads=120000, read_len=rl, start=start, p_sub=0.35, p_rand=0.1, p_n=0.08, p_lowq=0.1)
+    with P.Counter(features=lib, **kw) as c:
+        fq = bytes(c.synth_fastq(**spec))
+        fq = sprinkle_symbols(fq, 3, rate=0.01) + bytes(c.synth_fastq(**dict(spec, n_reads=300, read_len=start + glen - 2)))
+        orc = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+        _, t = c.count_block(fq, want_timing=True)
+        counts, stats = c.read_counts()
+        assert list(stats) == orc.stats() and list(counts) == orc.counts()
+        assert t["general_reads"] == 0
+    monkeypatch.setenv("F2Q_NO_LT", "1")
+    with P.Counter(features=lib, **kw) as c:
+        c.count_block(fq)
+        counts2, stats2 = c.read_counts()
+    monkeypatch.delenv("F2Q_NO_LT")
+    assert list(stats2) == list(stats) and list(counts2) == list(counts)
+
+
+def test_lds_histogram_overflow_protocol(P, monkeypatch):
+    """two guides take 40M reads: every workgroup's u16 counters pass 0x8000 several times and hand the surplus to the
+    global vector; the result must equal the pigeonhole kernel's (u32 histogram) bit for bit"""
+    lib = P.binding.synth_library(77, 2, 20)
+    spec = dict(seed=9, n_reads=40_000_000, read_len=150)
+    kw = dict(miss=1, phred=30, length=20, start="0")
+    ca, sa, _, _ = _full(P, monkeypatch, {}, lib, spec, **kw)
+    cb, sb, _, _ = _full(P, monkeypatch, {"F2Q_NO_LT": "1"}, lib, spec, **kw)
+    assert (ca, sa) == (cb, sb) and sa[0] == 40_000_000 and sum(ca) == sa[1] + sa[2] and min(ca) > 10_000_000
 
 
 def test_library_is_built_from_this_tree(P):

@@ -76,6 +76,54 @@ def test_pigeonhole_vs_oracle_dense(miss, glen, n_guides, v2):
     assert stats == o.stats() and counts == o.counts()
 
 
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("glen,n_guides,start", [(20, 10000, 0), (20, 13000, 3), (14, 800, 5), (21, 6000, 2), (17, 2000, 9), (16, 3000, 0)])
+def test_lds_tables_vs_oracle(miss, glen, n_guides, start):
+    """k_count_fixed4_lds's per-read logic: cuckoo tables of half-keyed tags (exact hit + the unique feature at distance 1,
+    flagged symbols as forced mismatches) against the oracle, on libraries up to the LDS capacity, with heavy mutation so
+    that ties, multi-candidate reads and N symbols are common; and against the pigeonhole tables (lt=False)."""
+    guides = synth.make_library(n_guides, glen, 31 * glen + n_guides)
+    # near-duplicate features: many guides one substitution away from another one (ambiguous nearest neighbours)
+    twins = []
+    for i, g in enumerate(guides[:400]):
+        p = (i * 7) % glen
+        t = g[:p] + "ACGT"[("ACGT".index(g[p]) + 1 + i % 3) % 4] + g[p + 1:]
+        twins.append(t)
+    lib = list(dict.fromkeys(guides + twins))
+    spec = synth.Spec(seed=glen + miss, n_reads=6000, read_len=start + glen + 6, start=start, p_sub=0.35, p_rand=0.1, p_n=0.08, p_lowq=0.1)
+    fq = sprinkle_symbols(synth.make_fastq(spec, lib), 3, rate=0.01)
+    fq += synth.make_fastq(synth.Spec(seed=5, n_reads=50, read_len=start + glen - 2, start=start), lib)   # clipped windows
+    kw = dict(miss=miss, length=glen, start=str(start))
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    e = Emu(features=lib, **kw)
+    assert e.lt_ok()
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats() and counts == o.counts()
+    assert e.lt_reads() > 5000 and gen == 0
+    e2 = Emu(features=lib, lt=False, **kw)
+    e2.count_block(fq)
+    assert e2.read()[:2] == (counts, stats) and e2.lt_reads() == 0
+
+
+def test_lds_tables_applicability():
+    """built only for uniform ACGT libraries of 14..21-base features searched with --m <= 1 that fit the tables"""
+    g20 = synth.make_library(500, 20, 1)
+    assert Emu(features=g20, miss=1, length=20).lt_ok() and Emu(features=g20, miss=0, length=20).lt_ok()
+    assert not Emu(features=g20, miss=2, length=20).lt_ok()
+    assert not Emu(features=g20 + ["ACGTACGTACGTAC"], miss=1, length=20).lt_ok()            # mixed lengths
+    assert not Emu(features=g20[:-1] + [g20[-1][:5] + "N" + g20[-1][6:]], miss=1, length=20).lt_ok()   # irregular feature
+    assert not Emu(features=synth.make_library(300, 13, 2), miss=1, length=13).lt_ok()
+    assert not Emu(features=synth.make_library(300, 22, 2), miss=1, length=22).lt_ok()
+    assert not Emu(features=synth.make_library(15000, 20, 3), miss=1, length=20).lt_ok()     # beyond the LDS capacity
+    # shared halves: 3 features with one left half fit (2 buckets x 2 slots), 5 cannot -> no tables, pigeonhole kernel
+    left = "ACGTTGCAAC"
+    rights = ["AAAAAAAAAA", "CCCCCCCCCC", "GGGGGGGGGG", "TTTTTTTTTT", "ACACACACAC"]
+    assert Emu(features=[left + r for r in rights[:3]], miss=1, length=20).lt_ok()
+    assert not Emu(features=[left + r for r in rights], miss=1, length=20).lt_ok()
+
+
 @pytest.mark.parametrize("start,length", [(0, 20), (3, 20), (13, 17), (15, 31), (16, 16), (1, 1), (30, 5), (2, 0)])
 def test_window_geometry_sweep(start, length):
     # every alignment of the window against the 16-base / 4-quality word grid, plus clipped reads
