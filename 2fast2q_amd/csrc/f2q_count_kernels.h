@@ -332,7 +332,9 @@ __device__ __forceinline__ void lt_count(uint32_t *cnt, uint32_t slot, const Acc
     }
 }
 
-template <int NQ, int NB, bool NEAR>
+// A20: the window is 20 bases starting at a multiple of 16 (--l 20 with --st 0, 16, ...: the usual guide-counting run):
+// the key needs no shift, every quality row is tested whole, and the table geometry (two 10-base halves) is constant.
+template <int NQ, int NB, bool NEAR, bool A20>
 __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDev *__restrict__ runp,
                                                                      const LibDev *__restrict__ libp, PackedBlock pb,
                                                                      Accum acc)
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
     uint32_t *cnt = lt_smem + NT * F2Q_LT_SLOTS;                // [F2Q_LT_BUCKETS] two u16 counters per word
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
-    const LtDesc lt = lib.lt;
+    LtDesc lt = lib.lt;
+    if (A20) { lt.hb0 = 20u; lt.hb1 = 20u; lt.len = 20u; }      // constants for the compiler
     const uint32_t nf = lib.n_features;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     {
@@ -354,95 +357,112 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
         for (uint32_t i = tid; i < F2Q_LT_BUCKETS; i += F2Q_LT_THREADS) cnt[i] = 0;
     }
     __syncthreads();
-    const FixedGeom g = fixed_geom(run);
+    FixedGeom g = fixed_geom(run);
+    if (A20) { g.L = 20; g.nq = 5; g.nb = 2; g.sh = 0; g.qm_first = 0x80808080u; g.qm_last = 0x80808080u; g.kmask = (1ull << 40) - 1ull; }
     const int need = g.st + g.L;
-    const bool do_near = NEAR && run.miss > 0;
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+    // the five reference counters of this wave, kept in scalar registers: the per-read verdicts are lane masks already
+    uint32_t w_reads = 0, w_perfect = 0, w_imperfect = 0, w_qfail = 0;
     constexpr int QR = NQ ? NQ : F2Q_MAXQROWS, BR = NB ? NB : F2Q_MAXBROWS;
     constexpr bool PIPE = NQ != 0;                              // run-time geometry: 12 rows, too many to keep two tiles of
 
-    U4 nbrow[BR], nqrow[QR]; uint32_t nlen01 = 0, nlen23 = 0;
-    auto request_tile = [&](uint32_t t) {
+    struct Rows { U4 b[BR], q[QR]; uint32_t len01, len23; };
+    auto request_tile = [&](Rows &r, uint32_t t) {
         const auto qp = gp(pb.qual) + (uint64_t)t * pb.wq * F2Q_TILE + 4u * lane;
         const auto bp = gp(pb.bases) + (uint64_t)t * pb.wb * F2Q_TILE + 4u * lane;
 #pragma unroll
-        for (int r = 0; r < BR; r++) {
-            const uint32_t row = (uint32_t)g.bw0 + (uint32_t)(NB ? r : (r < g.nb ? r : g.nb - 1));   // the host checked: rows exist
-            nbrow[r] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
+        for (int i = 0; i < BR; i++) {
+            const uint32_t row = (uint32_t)g.bw0 + (uint32_t)(NB ? i : (i < g.nb ? i : g.nb - 1));   // the host checked: rows exist
+            r.b[i] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
         }
 #pragma unroll
-        for (int r = 0; r < QR; r++) {
-            const uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? r : (r < g.nq ? r : g.nq - 1));
-            nqrow[r] = ld_u4<true>(qp + (uint64_t)row * F2Q_TILE);
+        for (int i = 0; i < QR; i++) {
+            const uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? i : (i < g.nq ? i : g.nq - 1));
+            r.q[i] = ld_u4<true>(qp + (uint64_t)row * F2Q_TILE);
         }
+        r.len01 = 0; r.len23 = 0;
         if (pb.len) {
             typedef uint32_t v2 __attribute__((ext_vector_type(2)));
             const v2 lv = __builtin_nontemporal_load((const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)t * F2Q_TILE + 4u * lane));
-            nlen01 = lv.x; nlen23 = lv.y;
+            r.len01 = lv.x; r.len23 = lv.y;
         }
     };
-    const uint32_t stride = gridDim.x * F2Q_LT_WAVES;
-    uint32_t tile = blockIdx.x * F2Q_LT_WAVES + wave;
-    if (PIPE && tile < pb.n_tiles) request_tile(tile);
-    for (; tile < pb.n_tiles; tile += stride) {
-        if (!PIPE) request_tile(tile);
-        U4 brow[BR], qrow[QR];
-#pragma unroll
-        for (int r = 0; r < BR; r++) brow[r] = nbrow[r];
-#pragma unroll
-        for (int r = 0; r < QR; r++) qrow[r] = nqrow[r];
-        const uint32_t len01 = nlen01, len23 = nlen23;
-        if (PIPE) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (tile + stride < pb.n_tiles) request_tile(tile + stride);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    auto decide_tile = [&](const Rows &r) {
         uint32_t bad[4] = {0, 0, 0, 0};
         if (g.add_hi) {
+            if (A20) {
+                // every byte of the five rows is under the window: OR the rows' verdicts, mask once
 #pragma unroll
-            for (int r = 0; r < QR; r++)
-                if (NQ || r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
-        }
+                for (int i = 0; i < QR; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
-            int res;
-            if (l == F2Q_LEN_SKIP) res = R_SKIP;
-            // a read that ends inside the window gives a shorter key (:354); every feature is L long, so it can equal
-            // or approach none (:683); its bytes past the end are stored as 0 and never fail the Phred test
-            else if ((int)(l & 0x7FFFu) < need) res = bad[j] ? R_QFAIL : R_NONALIGNED;
-            else if (bad[j]) res = R_QFAIL;
-            else {
-                const uint64_t key = fixed4_key(g, brow, j);
-                uint32_t forced = 0;
-                if (l & F2Q_LEN_FLAG) forced = fixed4_flags(g, qrow, j);      // non-ACGT symbols in the window (rare)
-                const LtProbe q = lt_probe(lt, key);
-                U2 e[4];
-#pragma unroll
-                for (int k = 0; k < (NEAR ? 4 : 2); k++) e[k] = lds_u2(tg + (uint32_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q.b[k]);
-                if (!NEAR) { e[2] = U2{F2Q_LT_EMPTY, F2Q_LT_EMPTY}; e[3] = e[2]; }
-                res = R_NONALIGNED;
-                if (forced == 0u) {
-                    const int ex = lt_exact(lt, q, e[0], e[1]);
-                    if (ex >= 0) { res = R_PERFECT; lt_count(cnt, (uint32_t)ex, acc, lt); }
-                    else if (do_near) {
-                        uint32_t hit;
-                        if (lt_near1(lt, q, e, 0u, hit) == 1u) {
-                            const uint32_t slot = (hit >> 16) ? (uint32_t)gp(lt.xref)[hit & 0xFFFFu] : hit;
-                            res = R_IMPERFECT; lt_count(cnt, slot, acc, lt);
-                        }
-                    }
-                } else if (do_near && __popc(forced) <= run.miss) {
-                    uint32_t hit;
-                    if (lt_near1(lt, q, e, forced, hit) == 1u) {
-                        const uint32_t slot = (hit >> 16) ? (uint32_t)gp(lt.xref)[hit & 0xFFFFu] : hit;
-                        res = R_IMPERFECT; lt_count(cnt, slot, acc, lt);
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t w = u4get(r.q[i], j) & 0x7F7F7F7Fu;       // bit 7 = non-ACGT flag, not quality
+                        bad[j] |= (w + g.add_lo) & ~(w + g.add_hi);
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < 4; j++) bad[j] &= 0x80808080u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < QR; i++)
+                    if (NQ || i < g.nq) fixed4_qrow(g, i, r.q[i], bad);
             }
-            st0 += (res != R_SKIP); st1 += (res == R_PERFECT); st2 += (res == R_IMPERFECT);
-            st3 += (res == R_NONALIGNED); st4 += (res == R_QFAIL);
         }
+        // two reads at a time: both reads' eight bucket reads are in flight together, and nothing below branches except the
+        // rare cases (flagged symbols, features sharing a half, a hit found through table 1, a counter passing 0x8000)
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+            LtProbe q[2]; U2 e[2][4]; uint32_t forced[2]; bool cand[2];
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int j = jp + a;
+                const uint32_t l = pb.len ? (((j < 2 ? r.len01 : r.len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+                const bool live = l != F2Q_LEN_SKIP, qf = live && bad[j] != 0u;
+                // a read that ends inside the window gives a shorter key (:354); every feature is L long, so it can equal
+                // or approach none (:683); its bytes past the end are stored as 0 and never fail the Phred test
+                cand[a] = live && !qf && (int)(l & 0x7FFFu) >= need;
+                w_reads += (uint32_t)__popcll(__ballot(live));
+                w_qfail += (uint32_t)__popcll(__ballot(qf));
+                forced[a] = 0;
+                if ((l & F2Q_LEN_FLAG) && cand[a]) forced[a] = fixed4_flags(g, r.q, j);   // non-ACGT symbols in the window (rare)
+                q[a] = lt_probe(lt, fixed4_key(g, r.b, j));
+#pragma unroll
+                for (int k = 0; k < (NEAR ? 4 : 2); k++) e[a][k] = lds_u2(tg + (uint32_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q[a].b[k]);
+                if (!NEAR) { e[a][2] = U2{F2Q_LT_EMPTY, F2Q_LT_EMPTY}; e[a][3] = e[a][2]; }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                LtVerdict v; v.res = R_NONALIGNED; v.slot = 0;
+                if (forced[a] == 0u || (NEAR && __popc(forced[a]) <= 1))
+                    v = lt_decide<NEAR>(lt, q[a], e[a], forced[a], [&](uint32_t bk) { return lds_u2(tg + 2u * bk); });
+                const bool perfect = cand[a] && v.res == R_PERFECT, imperfect = cand[a] && v.res == R_IMPERFECT;
+                if (perfect | imperfect) lt_count(cnt, v.slot, acc, lt);
+                w_perfect += (uint32_t)__popcll(__ballot(perfect));
+                w_imperfect += (uint32_t)__popcll(__ballot(imperfect));
+            }
+        }
+    };
+
+    const uint32_t stride = gridDim.x * F2Q_LT_WAVES;
+    uint32_t tile = blockIdx.x * F2Q_LT_WAVES + wave;
+    if (PIPE) {
+        // two register sets of rows, used alternately: the next tile's rows travel while this tile is decided
+        Rows ra, rb;
+        if (tile < pb.n_tiles) request_tile(ra, tile);
+        while (tile < pb.n_tiles) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + stride < pb.n_tiles) request_tile(rb, tile + stride);
+            __builtin_amdgcn_sched_barrier(0);
+            decide_tile(ra);
+            tile += stride;
+            if (tile >= pb.n_tiles) break;
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + stride < pb.n_tiles) request_tile(ra, tile + stride);
+            __builtin_amdgcn_sched_barrier(0);
+            decide_tile(rb);
+            tile += stride;
+        }
+    } else {
+        for (; tile < pb.n_tiles; tile += stride) { Rows r; request_tile(r, tile); decide_tile(r); }
     }
     __syncthreads();
     // the histogram leaves as one slab row in feature order; k_reduce_slabs sums the rows
@@ -454,7 +474,10 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
         }
     }
     __syncthreads();
-    unsigned long long stv[5] = {st0, st1, st2, st3, st4};
+    // wave totals -> one stats row per workgroup (lane 0 of every wave carries its wave's counters)
+    const bool l0 = lane == 0;
+    unsigned long long stv[5] = {l0 ? w_reads : 0u, l0 ? w_perfect : 0u, l0 ? w_imperfect : 0u,
+                                 l0 ? w_reads - w_perfect - w_imperfect - w_qfail : 0u, l0 ? w_qfail : 0u};
     flush_stats(acc, stv, reinterpret_cast<unsigned long long *>(lt_smem), acc.stat_slab + (uint64_t)blockIdx.x * 8u);   // the tables are done with
 }
 

@@ -90,7 +90,6 @@ struct LtDesc {
     uint32_t len;                      // feature length L
     uint32_t hb0, hb1;                 // bits of half 0 (bases [0, L/2)) and half 1 (the rest)
     const uint32_t *tags;              // [2][F2Q_LT_SLOTS]: table t is bucketed by half t and stores the other half in its tags
-    const uint16_t *xref;              // [F2Q_LT_SLOTS] table-1 slot -> table-0 slot of the same feature
     const uint16_t *slot_of;           // [n_features] table-0 slot of a feature = its counter in the LDS histogram
     const uint32_t *feat_of;           // [F2Q_LT_SLOTS] feature of a table-0 slot (unused slots: 0)
 };
@@ -907,7 +906,7 @@ F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key
 //                                      there is exactly one (unique nearest, distance 1)
 // A flagged (non-ACGT) query base is a forced mismatch: with one of them the candidates are the entries of the table
 // bucketed by the clean half whose other half agrees everywhere else.  Counts go to a u16 histogram indexed by the
-// table-0 slot (lt_count); table-1 hits find that slot through xref.
+// table-0 slot (lt_count); a table-1 hit knows its feature's whole key and looks its table-0 slot up (lt_slot_of_t1).
 // ---------------------------------------------------------------------------------------------
 F2Q_HD uint32_t lt_mul24(uint32_t a, uint32_t b)
 {
@@ -923,9 +922,7 @@ F2Q_HD uint32_t lt_perm(uint32_t h, uint32_t bits, int c)
 {
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t v = lt_mul24(h, c ? 0x9E3779u : 0x85EBCBu) & mask;
-    v ^= v >> (bits - 10u);
-    v = lt_mul24(v, c ? 0x2C1B3Du : 0x297A2Du) & mask;
-    v ^= v >> (bits - F2Q_LT_BBITS + 3u);
+    v ^= v >> (bits - 10u);                    // the product's high bits are the well-mixed ones: fold them onto the bucket bits
     return v;
 }
 // choice c of half value h of table t: bucket and what (entry >> ob) must equal for "same half" (ob = bits of the other half)
@@ -967,19 +964,18 @@ F2Q_HD LtProbe lt_probe(const LtDesc &lt, uint64_t key)
     lt_hash(q.h1, lt.hb1, lt.hb0, 1, q.b[3], q.cmp[3]);
     return q;
 }
-// exact hit among the two table-0 buckets: slot or -1
+// exact hit among the two table-0 buckets: slot or -1 (branch-free: a key sits in at most one slot)
 F2Q_HD int lt_exact(const LtDesc &lt, const LtProbe &q, const U2 &e0, const U2 &e1)
 {
     const uint32_t w0 = lt_tag(q.cmp[0], q.h1, lt.hb1), w1 = lt_tag(q.cmp[1], q.h1, lt.hb1);
-    if (e0.x == w0) return (int)(2u * q.b[0]);
-    if (e0.y == w0) return (int)(2u * q.b[0] + 1u);
-    if (e1.x == w1) return (int)(2u * q.b[1]);
-    if (e1.y == w1) return (int)(2u * q.b[1] + 1u);
-    return -1;
+    const bool a0 = e0.x == w0, a1 = e0.y == w0, b0 = e1.x == w1, b1 = e1.y == w1;
+    const uint32_t slot = (a0 | a1) ? 2u * q.b[0] + (uint32_t)a1 : 2u * q.b[1] + (uint32_t)b1;
+    return (a0 | a1 | b0 | b1) ? (int)slot : -1;
 }
 // candidates at distance exactly 1 among the four buckets e[0..3] (see the section comment).  forced: one bit per base
-// of the window that mismatches every feature.  Returns the number of candidates; hit = table (0/1) << 16 | slot of one.
-F2Q_HD uint32_t lt_near1(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], uint32_t forced, uint32_t &hit)
+// of the window that mismatches every feature.  Returns the number of candidates; for one of them: hit = table (0/1)
+// << 16 | its slot in that table, hitw = its tag.
+F2Q_HD uint32_t lt_near1(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], uint32_t forced, uint32_t &hit, uint32_t &hitw)
 {
     const uint32_t l0 = lt.hb0 >> 1;
     const uint32_t f0 = forced & ((1u << l0) - 1u), f1 = forced >> l0;
@@ -994,23 +990,106 @@ F2Q_HD uint32_t lt_near1(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], u
         keep0 = ~(s0 | (s0 << 1)); keep1 = ~(s1 | (s1 << 1));
     }
     uint32_t n = 0;
-    hit = 0;
+    hit = 0; hitw = 0;
     const uint32_t m0 = (1u << lt.hb0) - 1u, m1 = (1u << lt.hb1) - 1u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const bool t1 = k >= 2;                       // table 1: same half 1, other half = half 0
-        if (t1 ? (f1 != 0u) : (f0 != 0u)) continue;   // a flagged base in the bucketing half: it can agree with nothing
+        // a flagged base in the bucketing half: that half can agree with nothing
+        const bool open = t1 ? (f1 == 0u) : (f0 == 0u);
         const uint32_t ob = t1 ? lt.hb0 : lt.hb1, om = t1 ? m0 : m1, oq = t1 ? q.h0 : q.h1, keep = t1 ? keep0 : keep1;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const uint32_t w = i ? e[k].y : e[k].x;
             const bool same = (w >> ob) == q.cmp[k];
             const uint32_t d = ham2_32(((w ^ oq) & om) & keep) + nf;
-            if (same && d == 1u) { n++; hit = ((uint32_t)t1 << 16) | (2u * q.b[k] + (uint32_t)i); }
+            const bool c = open & same & (d == 1u);
+            n += (uint32_t)c;
+            hit = c ? (((uint32_t)t1 << 16) | (2u * q.b[k] + (uint32_t)i)) : hit;
+            hitw = c ? w : hitw;
         }
     }
     return n;
 }
+// the table-0 slot (= histogram counter) of the feature a table-1 entry stands for: the entry's tag holds the feature's
+// half 0, the bucket it was found through its half 1, so the feature's key is known and table 0 is probed for it.
+// rd(bucket) reads the two tags of a table-0 bucket.
+template <class RD>
+F2Q_HD uint32_t lt_slot_of_t1(const LtDesc &lt, const LtProbe &q, uint32_t hitw, RD rd)
+{
+    const uint32_t fh0 = hitw & ((1u << lt.hb0) - 1u);
+    uint32_t b0, c0, b1, c1;
+    lt_hash(fh0, lt.hb0, lt.hb1, 0, b0, c0); lt_hash(fh0, lt.hb0, lt.hb1, 1, b1, c1);
+    const U2 e0 = rd(b0), e1 = rd(b1);
+    const uint32_t w0 = lt_tag(c0, q.h1, lt.hb1), w1 = lt_tag(c1, q.h1, lt.hb1);
+    const bool a1 = e0.y == w0, hit0 = (e0.x == w0) | a1, b1y = e1.y == w1;
+    return hit0 ? 2u * b0 + (uint32_t)a1 : 2u * b1 + (uint32_t)b1y;
+}
+
+// One table's answer for a query, the cheap way: every tag of the query's two buckets is XORed with the tag the query
+// itself would have there (same choice, same scrambled half, the query's own other half).  x < 2^ob <=> the entry has the
+// query's half (an empty slot or a tag of another half or choice differs above bit ob), and then x is the difference
+// of the other halves: 0 = the query itself, one base pair set = distance 1.  Almost always at most one entry of a
+// table has the query's half (several features would have to share a half): that entry is picked by priority select,
+// `multi` reports the other case, which takes the general routine (lt_near1).
+struct LtSide { uint32_t x, slot; bool any, multi, first; };
+F2Q_HD LtSide lt_side(uint32_t want0, uint32_t want1, uint32_t limit, uint32_t b0, uint32_t b1, const U2 &e0, const U2 &e1)
+{
+    const uint32_t x0 = e0.x ^ want0, x1 = e0.y ^ want0, x2 = e1.x ^ want1, x3 = e1.y ^ want1;
+    const bool s0 = x0 < limit, s1 = x1 < limit, s2 = x2 < limit, s3 = x3 < limit;
+    LtSide r;
+    r.x = s0 ? x0 : s1 ? x1 : s2 ? x2 : x3;
+    r.slot = s0 ? 2u * b0 : s1 ? 2u * b0 + 1u : s2 ? 2u * b1 : 2u * b1 + 1u;
+    r.first = s0 | s1;
+    r.any = s0 | s1 | s2 | s3;
+    r.multi = (s0 & (s1 | s2 | s3)) | (s1 & (s2 | s3)) | (s2 & s3);
+    return r;
+}
+// The Counter-mode decision of one read from its four buckets: R_PERFECT / R_IMPERFECT / R_NONALIGNED and the
+// histogram slot to bump.  NEAR = run with --m 1 (false: --m 0, table 0 only, e[2..3] unused).  rd0(bucket) reads a
+// table-0 bucket (needed when the unique neighbour was found through table 1).
+struct LtVerdict { int res; uint32_t slot; };
+template <bool NEAR, class RD>
+F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], uint32_t forced, RD rd0)
+{
+    LtVerdict v; v.res = R_NONALIGNED; v.slot = 0;
+    const uint32_t w0 = lt_tag(q.cmp[0], q.h1, lt.hb1), w1 = lt_tag(q.cmp[1], q.h1, lt.hb1);
+    const LtSide a = lt_side(w0, w1, 1u << lt.hb1, q.b[0], q.b[1], e[0], e[1]);
+    LtSide b; b.x = 0; b.slot = 0; b.any = false; b.multi = false; b.first = false;
+    uint32_t w2 = 0, w3 = 0;
+    if (NEAR) {
+        w2 = lt_tag(q.cmp[2], q.h0, lt.hb0); w3 = lt_tag(q.cmp[3], q.h0, lt.hb0);
+        b = lt_side(w2, w3, 1u << lt.hb0, q.b[2], q.b[3], e[2], e[3]);
+    }
+    if (forced == 0u && !a.multi && !b.multi) {
+        if (a.any && a.x == 0u) { v.res = R_PERFECT; v.slot = a.slot; return v; }
+        if (!NEAR) return v;
+        const bool c0 = a.any && ham2_32(a.x) == 1u, c1 = b.any && ham2_32(b.x) == 1u;
+        if (c0 != c1) {                                   // exactly one feature at distance 1
+            v.res = R_IMPERFECT;
+            v.slot = c0 ? a.slot : lt_slot_of_t1(lt, q, b.x ^ (b.first ? w2 : w3), rd0);
+        }
+        return v;
+    }
+    // flagged symbols, or several features sharing one of the query's halves: the general routine
+    if (forced == 0u) {
+        const int ex = lt_exact(lt, q, e[0], e[1]);
+        if (ex >= 0) { v.res = R_PERFECT; v.slot = (uint32_t)ex; return v; }
+    }
+    if (!NEAR) return v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__popc(forced) > 1) return v;
+#else
+    if (__builtin_popcount(forced) > 1) return v;
+#endif
+    uint32_t hit = 0, hitw = 0;
+    if (lt_near1(lt, q, e, forced, hit, hitw) == 1u) {
+        v.res = R_IMPERFECT;
+        v.slot = (hit >> 16) ? lt_slot_of_t1(lt, q, hitw, rd0) : (hit & 0xFFFFu);
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fast path, anchored (--us / --ds): one lane = one read held as two bit-planes.
 // Planar tile layout (anchored runs): base rows 0..NW-1 hold the LOW bit of 32 bases per word,

@@ -27,7 +27,7 @@ struct HostIndex {
     // LDS tables (f2q_device.h: LtDesc); lt.ok == 0: not applicable / the cuckoo build failed
     LtDesc lt{};
     std::vector<uint32_t> lt_tags, lt_feat_of;
-    std::vector<uint16_t> lt_xref, lt_slot_of;
+    std::vector<uint16_t> lt_slot_of;
     LenGroup grp[F2Q_REG_MAXLEN + 1];
     uint32_t n_features = 0, n_irregular = 0;
 };
@@ -104,7 +104,7 @@ inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int le
 inline void build_lt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, int miss)
 {
     memset(&ix.lt, 0, sizeof ix.lt);
-    ix.lt_tags.assign(1, F2Q_LT_EMPTY); ix.lt_feat_of.assign(1, 0); ix.lt_xref.assign(1, 0); ix.lt_slot_of.assign(1, 0);
+    ix.lt_tags.assign(1, F2Q_LT_EMPTY); ix.lt_feat_of.assign(1, 0); ix.lt_slot_of.assign(1, 0);
     if (len < 14 || len > 21 || miss > 1 || ids.empty() || ids.size() != ix.n_features) return;
     if (ids.size() > (size_t)(F2Q_LT_SLOTS * 0.87)) return;
     LtDesc lt{};
@@ -148,11 +148,9 @@ inline void build_lt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, i
             if (!placed) return;                       // no LDS tables for this library (lt.ok stays 0)
         }
     }
-    ix.lt_slot_of.assign(ix.n_features, 0); ix.lt_feat_of.assign(F2Q_LT_SLOTS, 0); ix.lt_xref.assign(F2Q_LT_SLOTS, 0);
+    ix.lt_slot_of.assign(ix.n_features, 0); ix.lt_feat_of.assign(F2Q_LT_SLOTS, 0);
     for (uint32_t s = 0; s < F2Q_LT_SLOTS; s++)
         if (owner[s] != ~0u) { ix.lt_slot_of[owner[s]] = (uint16_t)s; ix.lt_feat_of[s] = owner[s]; }
-    for (uint32_t s = 0; s < F2Q_LT_SLOTS; s++)
-        if (owner[F2Q_LT_SLOTS + s] != ~0u) ix.lt_xref[s] = ix.lt_slot_of[owner[F2Q_LT_SLOTS + s]];
     ix.lt_tags.swap(tags);
     lt.ok = 1;
     ix.lt = lt;

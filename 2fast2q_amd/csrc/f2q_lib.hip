@@ -220,12 +220,11 @@ static int upload_lib(f2q_ctx *c)
     if ((rc = dev_upload(c, c->ix.ptab.data(), c->ix.ptab.size(), &pt, c->lib_allocs))) return rc;
     L.ptab = pt;
     {
-        uint32_t *lt_tags, *lt_feat; uint16_t *lt_xref, *lt_slot;
+        uint32_t *lt_tags, *lt_feat; uint16_t *lt_slot;
         if ((rc = dev_upload(c, c->ix.lt_tags.data(), c->ix.lt_tags.size(), &lt_tags, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.lt_feat_of.data(), c->ix.lt_feat_of.size(), &lt_feat, c->lib_allocs))) return rc;
-        if ((rc = dev_upload(c, c->ix.lt_xref.data(), c->ix.lt_xref.size(), &lt_xref, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.lt_slot_of.data(), c->ix.lt_slot_of.size(), &lt_slot, c->lib_allocs))) return rc;
-        L.lt = c->ix.lt; L.lt.tags = lt_tags; L.lt.feat_of = lt_feat; L.lt.xref = lt_xref; L.lt.slot_of = lt_slot;
+        L.lt = c->ix.lt; L.lt.tags = lt_tags; L.lt.feat_of = lt_feat; L.lt.slot_of = lt_slot;
     }
     L.tab_keys = tk; L.tab_idx = ti; L.feat_bytes = fb; L.feat_off = fo; L.irr_ids = ir;
     c->guide_keys_d = gk;
@@ -530,8 +529,9 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
             const bool near = c->run_h.miss > 0;
             const size_t shmem = ((near ? 2u : 1u) * (size_t)F2Q_LT_SLOTS + F2Q_LT_BUCKETS) * 4;
             const bool spec52 = !c->force_generic && fgeo.nq == 5 && fgeo.nb == 2 && c->run_h.thr >= 33;
-            auto kern = near ? (spec52 ? k_count_fixed4_lds<5, 2, true> : k_count_fixed4_lds<0, 0, true>)
-                             : (spec52 ? k_count_fixed4_lds<5, 2, false> : k_count_fixed4_lds<0, 0, false>);
+            const bool a20 = spec52 && fgeo.L == 20 && (fgeo.st & 15) == 0;
+            auto kern = near ? (a20 ? k_count_fixed4_lds<5, 2, true, true> : spec52 ? k_count_fixed4_lds<5, 2, true, false> : k_count_fixed4_lds<0, 0, true, false>)
+                             : (a20 ? k_count_fixed4_lds<5, 2, false, true> : spec52 ? k_count_fixed4_lds<5, 2, false, false> : k_count_fixed4_lds<0, 0, false, false>);
             const uint32_t nf_ = c->lib_h.n_features;
             const size_t need = (size_t)grid * nf_;
             if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {

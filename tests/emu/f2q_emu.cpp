@@ -35,7 +35,7 @@ static void bind_lib(Emu *e)
     L.tab_keys = e->ix.tab_keys.data(); L.tab_idx = e->ix.tab_idx.data();
     L.ptab = e->ix.ptab.data(); L.pk = e->ix.pk;
     L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
-    L.lt = e->ix.lt; L.lt.tags = e->ix.lt_tags.data(); L.lt.xref = e->ix.lt_xref.data(); L.lt.slot_of = e->ix.lt_slot_of.data();
+    L.lt = e->ix.lt; L.lt.tags = e->ix.lt_tags.data(); L.lt.slot_of = e->ix.lt_slot_of.data();
     L.lt.feat_of = e->ix.lt_feat_of.data();
     memcpy(L.grp, e->ix.grp, sizeof L.grp);
     e->acc.assign(e->ix.n_features + 5, 0);
@@ -269,12 +269,13 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                             const uint32_t *tb = lt.tags + (size_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q.b[k];
                             en[k] = U2{tb[0], tb[1]};
                         }
-                        uint32_t slot = 0, hit = 0;
-                        const int ex = forced ? -1 : lt_exact(lt, q, en[0], en[1]);
-                        if (ex >= 0) { res = R_PERFECT; slot = (uint32_t)ex; }
-                        else if (e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss) res = R_NONALIGNED;
-                        else if (lt_near1(lt, q, en, forced, hit) == 1u) { res = R_IMPERFECT; slot = (hit >> 16) ? lt.xref[hit & 0xFFFFu] : (hit & 0xFFFFu); }
-                        else res = R_NONALIGNED;
+                        auto rd0 = [&](uint32_t bk) { return U2{lt.tags[2u * bk], lt.tags[2u * bk + 1u]}; };
+                        uint32_t slot = 0;
+                        if (forced && (e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss)) res = R_NONALIGNED;
+                        else {
+                            const LtVerdict v = e->run.miss > 0 ? lt_decide<true>(lt, q, en, forced, rd0) : lt_decide<false>(lt, q, en, forced, rd0);
+                            res = v.res; slot = v.slot;
+                        }
                         idx = lt.feat_of[slot];
                         e->lt_reads++;
                     }
