@@ -366,25 +366,23 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
     constexpr bool PIPE = NQ != 0;                              // run-time geometry: 12 rows, too many to keep two tiles of
 
     struct Rows { U4 b[BR], q[QR]; uint32_t len01, len23; };
+    // All loads of a tile are unconditional and their number is fixed (the host guarantees the rows and the length plane
+    // exist): the compiler's s_waitcnt bookkeeping is then exact, and waiting for this tile's rows does not also wait
+    // for the next tile's, which were requested after them.  One 64-bit address per plane, the rows at immediate offsets.
+    const uint64_t q_stride = (uint64_t)pb.wq * F2Q_TILE, b_stride = (uint64_t)pb.wb * F2Q_TILE;
+    const auto q_base = gp(pb.qual) + (uint64_t)g.qw0 * F2Q_TILE + 4u * lane;
+    const auto b_base = gp(pb.bases) + (uint64_t)g.bw0 * F2Q_TILE + 4u * lane;
+    const auto l_base = gp(pb.len) + 4u * lane;
     auto request_tile = [&](Rows &r, uint32_t t) {
-        const auto qp = gp(pb.qual) + (uint64_t)t * pb.wq * F2Q_TILE + 4u * lane;
-        const auto bp = gp(pb.bases) + (uint64_t)t * pb.wb * F2Q_TILE + 4u * lane;
+        const auto qp = q_base + (uint64_t)t * q_stride;
+        const auto bp = b_base + (uint64_t)t * b_stride;
 #pragma unroll
-        for (int i = 0; i < BR; i++) {
-            const uint32_t row = (uint32_t)g.bw0 + (uint32_t)(NB ? i : (i < g.nb ? i : g.nb - 1));   // the host checked: rows exist
-            r.b[i] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
-        }
+        for (int i = 0; i < BR; i++) r.b[i] = ld_u4<true>(bp + (NB ? i : (i < g.nb ? i : g.nb - 1)) * F2Q_TILE);
 #pragma unroll
-        for (int i = 0; i < QR; i++) {
-            const uint32_t row = (uint32_t)g.qw0 + (uint32_t)(NQ ? i : (i < g.nq ? i : g.nq - 1));
-            r.q[i] = ld_u4<true>(qp + (uint64_t)row * F2Q_TILE);
-        }
-        r.len01 = 0; r.len23 = 0;
-        if (pb.len) {
-            typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-            const v2 lv = __builtin_nontemporal_load((const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)t * F2Q_TILE + 4u * lane));
-            r.len01 = lv.x; r.len23 = lv.y;
-        }
+        for (int i = 0; i < QR; i++) r.q[i] = ld_u4<true>(qp + (NQ ? i : (i < g.nq ? i : g.nq - 1)) * F2Q_TILE);
+        typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+        const v2 lv = __builtin_nontemporal_load((const v2 F2Q_GLOBAL *)(l_base + (uint64_t)t * F2Q_TILE));
+        r.len01 = lv.x; r.len23 = lv.y;
     };
     auto decide_tile = [&](const Rows &r) {
         uint32_t bad[4] = {0, 0, 0, 0};
@@ -415,7 +413,7 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const int j = jp + a;
-                const uint32_t l = pb.len ? (((j < 2 ? r.len01 : r.len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+                const uint32_t l = ((j < 2 ? r.len01 : r.len23) >> (16 * (j & 1))) & 0xFFFFu;
                 const bool live = l != F2Q_LEN_SKIP, qf = live && bad[j] != 0u;
                 // a read that ends inside the window gives a shorter key (:354); every feature is L long, so it can equal
                 // or approach none (:683); its bytes past the end are stored as 0 and never fail the Phred test
@@ -431,35 +429,38 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
             }
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                LtVerdict v; v.res = R_NONALIGNED; v.slot = 0;
-                if (forced[a] == 0u || (NEAR && __popc(forced[a]) <= 1))
-                    v = lt_decide<NEAR>(lt, q[a], e[a], forced[a], [&](uint32_t bk) { return lds_u2(tg + 2u * bk); });
-                const bool perfect = cand[a] && v.res == R_PERFECT, imperfect = cand[a] && v.res == R_IMPERFECT;
-                if (perfect | imperfect) lt_count(cnt, v.slot, acc, lt);
-                w_perfect += (uint32_t)__popcll(__ballot(perfect));
-                w_imperfect += (uint32_t)__popcll(__ballot(imperfect));
+                const LtVerdict v = lt_decide<NEAR>(lt, q[a], e[a], forced[a], [&](uint32_t bk) { return lds_u2(tg + 2u * bk); });
+                const LtPred cm = LT_P(cand[a]), perfect = v.perfect & cm, imperfect = v.imperfect & cm;
+                if (LT_TRUE(perfect | imperfect)) lt_count(cnt, v.slot, acc, lt);
+                w_perfect += (uint32_t)__popcll(perfect);
+                w_imperfect += (uint32_t)__popcll(imperfect);
             }
         }
     };
 
     const uint32_t stride = gridDim.x * F2Q_LT_WAVES;
     uint32_t tile = blockIdx.x * F2Q_LT_WAVES + wave;
+    const uint32_t last = pb.n_tiles - 1u;
     if (PIPE) {
-        // two register sets of rows, used alternately: the next tile's rows travel while this tile is decided
+        // two register sets of rows, used alternately: the next tile's rows travel while this tile is decided (past the
+        // end the last tile is requested again and dropped: an unconditional request keeps the wait counts exact)
         Rows ra, rb;
-        if (tile < pb.n_tiles) request_tile(ra, tile);
-        while (tile < pb.n_tiles) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (tile + stride < pb.n_tiles) request_tile(rb, tile + stride);
-            __builtin_amdgcn_sched_barrier(0);
-            decide_tile(ra);
-            tile += stride;
-            if (tile >= pb.n_tiles) break;
-            __builtin_amdgcn_sched_barrier(0);
-            if (tile + stride < pb.n_tiles) request_tile(ra, tile + stride);
-            __builtin_amdgcn_sched_barrier(0);
-            decide_tile(rb);
-            tile += stride;
+        if (tile < pb.n_tiles) {
+            request_tile(ra, tile);
+            for (;;) {
+                __builtin_amdgcn_sched_barrier(0);
+                request_tile(rb, min(tile + stride, last));
+                __builtin_amdgcn_sched_barrier(0);
+                decide_tile(ra);
+                tile += stride;
+                if (tile >= pb.n_tiles) break;
+                __builtin_amdgcn_sched_barrier(0);
+                request_tile(ra, min(tile + stride, last));
+                __builtin_amdgcn_sched_barrier(0);
+                decide_tile(rb);
+                tile += stride;
+                if (tile >= pb.n_tiles) break;
+            }
         }
     } else {
         for (; tile < pb.n_tiles; tile += stride) { Rows r; request_tile(r, tile); decide_tile(r); }

@@ -911,7 +911,11 @@ F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key
 F2Q_HD uint32_t lt_mul24(uint32_t a, uint32_t b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__umul24(a, b);          // both operands < 2^24: one full-rate v_mul_u32_u24
+    // both operands < 2^24: one full-rate v_mul_u32_u24.  As an asm statement: the optimiser otherwise merges the
+    // caller's mask into a 32-bit v_mul_lo_u32, which issues at a quarter of the rate
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
 #else
     return a * b;
 #endif
@@ -1026,67 +1030,88 @@ F2Q_HD uint32_t lt_slot_of_t1(const LtDesc &lt, const LtProbe &q, uint32_t hitw,
     return hit0 ? 2u * b0 + (uint32_t)a1 : 2u * b1 + (uint32_t)b1y;
 }
 
+// Lane predicates.  On the device a predicate is a 64-bit lane mask in scalar registers (what v_cmp writes): boolean
+// algebra on it runs on the scalar unit, beside the vector instructions, and selecting by it costs nothing extra.
+// On the host (tests/emu) it is a bool.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned long long LtPred;
+#define LT_P(c) __ballot(c)
+#define LT_TRUE(p) __builtin_amdgcn_inverse_ballot_w64(p)
+#define LT_NOT(p) (~(p))
+#else
+typedef bool LtPred;
+#define LT_P(c) (c)
+#define LT_TRUE(p) (p)
+#define LT_NOT(p) (!(p))
+#endif
+#define LT_SEL(p, a, b) (LT_TRUE(p) ? (a) : (b))
+
 // One table's answer for a query, the cheap way: every tag of the query's two buckets is XORed with the tag the query
 // itself would have there (same choice, same scrambled half, the query's own other half).  x < 2^ob <=> the entry has the
 // query's half (an empty slot or a tag of another half or choice differs above bit ob), and then x is the difference
 // of the other halves: 0 = the query itself, one base pair set = distance 1.  Almost always at most one entry of a
 // table has the query's half (several features would have to share a half): that entry is picked by priority select,
 // `multi` reports the other case, which takes the general routine (lt_near1).
-struct LtSide { uint32_t x, slot; bool any, multi, first; };
+struct LtSide { uint32_t x, slot; LtPred any, multi, first; };
 F2Q_HD LtSide lt_side(uint32_t want0, uint32_t want1, uint32_t limit, uint32_t b0, uint32_t b1, const U2 &e0, const U2 &e1)
 {
     const uint32_t x0 = e0.x ^ want0, x1 = e0.y ^ want0, x2 = e1.x ^ want1, x3 = e1.y ^ want1;
-    const bool s0 = x0 < limit, s1 = x1 < limit, s2 = x2 < limit, s3 = x3 < limit;
+    const LtPred s0 = LT_P(x0 < limit), s1 = LT_P(x1 < limit), s2 = LT_P(x2 < limit), s3 = LT_P(x3 < limit);
     LtSide r;
-    r.x = s0 ? x0 : s1 ? x1 : s2 ? x2 : x3;
-    r.slot = s0 ? 2u * b0 : s1 ? 2u * b0 + 1u : s2 ? 2u * b1 : 2u * b1 + 1u;
+    r.x = LT_SEL(s0, x0, LT_SEL(s1, x1, LT_SEL(s2, x2, x3)));
     r.first = s0 | s1;
-    r.any = s0 | s1 | s2 | s3;
+    r.any = r.first | s2 | s3;
     r.multi = (s0 & (s1 | s2 | s3)) | (s1 & (s2 | s3)) | (s2 & s3);
+    const LtPred odd = (LT_NOT(s0) & s1) | (LT_NOT(r.first) & LT_NOT(s2));      // the second slot of its bucket
+    r.slot = 2u * LT_SEL(r.first, b0, b1) + (LT_TRUE(odd) ? 1u : 0u);
     return r;
 }
-// The Counter-mode decision of one read from its four buckets: R_PERFECT / R_IMPERFECT / R_NONALIGNED and the
-// histogram slot to bump.  NEAR = run with --m 1 (false: --m 0, table 0 only, e[2..3] unused).  rd0(bucket) reads a
-// table-0 bucket (needed when the unique neighbour was found through table 1).
-struct LtVerdict { int res; uint32_t slot; };
+// The Counter-mode decision of one read from its four buckets: is it a perfect hit, is it the unique feature at
+// distance 1, and the histogram slot to bump.  NEAR = run with --m 1 (false: --m 0, table 0 only, e[2..3] unused).
+// rd0(bucket) reads a table-0 bucket (needed when the unique neighbour was found through table 1).
+struct LtVerdict { LtPred perfect, imperfect; uint32_t slot; };
 template <bool NEAR, class RD>
 F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], uint32_t forced, RD rd0)
 {
-    LtVerdict v; v.res = R_NONALIGNED; v.slot = 0;
     const uint32_t w0 = lt_tag(q.cmp[0], q.h1, lt.hb1), w1 = lt_tag(q.cmp[1], q.h1, lt.hb1);
     const LtSide a = lt_side(w0, w1, 1u << lt.hb1, q.b[0], q.b[1], e[0], e[1]);
-    LtSide b; b.x = 0; b.slot = 0; b.any = false; b.multi = false; b.first = false;
+    LtSide b = a;
     uint32_t w2 = 0, w3 = 0;
+    LtPred fast = LT_P(forced == 0u) & LT_NOT(a.multi);
+    LtPred perfect = fast & a.any & LT_P(a.x == 0u), near = perfect & LT_NOT(perfect);      // near = false
+    uint32_t slot = a.slot;
     if (NEAR) {
         w2 = lt_tag(q.cmp[2], q.h0, lt.hb0); w3 = lt_tag(q.cmp[3], q.h0, lt.hb0);
         b = lt_side(w2, w3, 1u << lt.hb0, q.b[2], q.b[3], e[2], e[3]);
-    }
-    if (forced == 0u && !a.multi && !b.multi) {
-        if (a.any && a.x == 0u) { v.res = R_PERFECT; v.slot = a.slot; return v; }
-        if (!NEAR) return v;
-        const bool c0 = a.any && ham2_32(a.x) == 1u, c1 = b.any && ham2_32(b.x) == 1u;
-        if (c0 != c1) {                                   // exactly one feature at distance 1
-            v.res = R_IMPERFECT;
-            v.slot = c0 ? a.slot : lt_slot_of_t1(lt, q, b.x ^ (b.first ? w2 : w3), rd0);
-        }
-        return v;
+        fast = fast & LT_NOT(b.multi);
+        perfect = perfect & fast;
+        const LtPred c0 = a.any & LT_P(ham2_32(a.x) == 1u), c1 = b.any & LT_P(ham2_32(b.x) == 1u);
+        near = fast & LT_NOT(perfect) & (c0 ^ c1);            // exactly one feature at distance 1
+        const LtPred via1 = near & c1;
+        if (LT_TRUE(via1)) slot = lt_slot_of_t1(lt, q, b.x ^ LT_SEL(b.first, w2, w3), rd0);
     }
     // flagged symbols, or several features sharing one of the query's halves: the general routine
-    if (forced == 0u) {
-        const int ex = lt_exact(lt, q, e[0], e[1]);
-        if (ex >= 0) { v.res = R_PERFECT; v.slot = (uint32_t)ex; return v; }
-    }
-    if (!NEAR) return v;
+    int sres = 0;
+    if (!LT_TRUE(fast)) {
+        sres = R_NONALIGNED;
+        const int ex = forced == 0u ? lt_exact(lt, q, e[0], e[1]) : -1;
+        if (ex >= 0) { sres = R_PERFECT; slot = (uint32_t)ex; }
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (__popc(forced) > 1) return v;
+        else if (NEAR && __popc(forced) <= 1) {
 #else
-    if (__builtin_popcount(forced) > 1) return v;
+        else if (NEAR && __builtin_popcount(forced) <= 1) {
 #endif
-    uint32_t hit = 0, hitw = 0;
-    if (lt_near1(lt, q, e, forced, hit, hitw) == 1u) {
-        v.res = R_IMPERFECT;
-        v.slot = (hit >> 16) ? lt_slot_of_t1(lt, q, hitw, rd0) : (hit & 0xFFFFu);
+            uint32_t hit = 0, hitw = 0;
+            if (lt_near1(lt, q, e, forced, hit, hitw) == 1u) {
+                sres = R_IMPERFECT;
+                slot = (hit >> 16) ? lt_slot_of_t1(lt, q, hitw, rd0) : (hit & 0xFFFFu);
+            }
+        }
     }
+    LtVerdict v;
+    v.perfect = perfect | LT_P(sres == R_PERFECT);
+    v.imperfect = near | LT_P(sres == R_IMPERFECT);
+    v.slot = slot;
     return v;
 }
 

@@ -522,7 +522,8 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         const FixedGeom fgeo = fixed_geom(c->run_h);
         // the library in LDS: uniform 14..21-base library, --m <= 1, and tiles that hold every row under the window
         const bool use_lt = v2 && lds && !c->no_lt && c->lib_h.lt.ok && c->lib_h.lt.len == (uint32_t)c->run_h.length &&
-                            c->run_h.miss <= 1 && (uint32_t)(fgeo.qw0 + fgeo.nq) <= pb.wq && (uint32_t)(fgeo.bw0 + fgeo.nb) <= pb.wb;
+                            c->run_h.miss <= 1 && (uint32_t)(fgeo.qw0 + fgeo.nq) <= pb.wq && (uint32_t)(fgeo.bw0 + fgeo.nb) <= pb.wb &&
+                            pb.len != nullptr;
         if (use_lt) {
             const uint32_t wgs = (pb.n_tiles + F2Q_LT_WAVES - 1) / F2Q_LT_WAVES;
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu);

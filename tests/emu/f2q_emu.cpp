@@ -274,7 +274,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                         if (forced && (e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss)) res = R_NONALIGNED;
                         else {
                             const LtVerdict v = e->run.miss > 0 ? lt_decide<true>(lt, q, en, forced, rd0) : lt_decide<false>(lt, q, en, forced, rd0);
-                            res = v.res; slot = v.slot;
+                            res = v.perfect ? R_PERFECT : v.imperfect ? R_IMPERFECT : R_NONALIGNED; slot = v.slot;
                         }
                         idx = lt.feat_of[slot];
                         e->lt_reads++;
