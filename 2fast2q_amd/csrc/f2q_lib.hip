@@ -1051,6 +1051,15 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
     for (auto &b : buf) if (!g_pinned.acquire(HEAD + CH, b)) { drop(); return fail(c, F2Q_ENOMEM, "cannot allocate the read buffers"); }
     const double tr_b = now_ms();
 
+    // the second stream is made before the reader thread exists: no early return may leave a joinable thread behind
+    const bool can_stage = world == 1 && !c->host_pack && !getenv("F2Q_NO_STAGING");
+    const bool force_stage = getenv("F2Q_FORCE_STAGING") != nullptr;
+    if (can_stage && !c->copy_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming);
+        if (e != hipSuccess) { drop(); return fail(c, F2Q_EHIP, std::string("copy stream: ") + hipGetErrorString(e)); }
+    }
+
     struct Piece { int slot; size_t n; };
     std::mutex mu; std::condition_variable cv;
     std::deque<Piece> ready; bool slot_free[NSLOT]; for (bool &f : slot_free) f = true; bool stop = false;
@@ -1073,12 +1082,6 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
     // the 16-byte boundary below it and the text are filled with 'x': they lengthen the first line, which is a record's
     // header line and is never looked at (fast2q.py:324-328 takes lines 2 and 4 only).
     struct Staged { void *buf = nullptr; size_t cap = 0; int slot = -1; size_t n = 0; } staged;
-    const bool can_stage = world == 1 && !c->host_pack && !getenv("F2Q_NO_STAGING");
-    const bool force_stage = getenv("F2Q_FORCE_STAGING") != nullptr;
-    if (can_stage && !c->copy_stream) {
-        HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        HIPC(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
-    }
     auto unstage = [&]() {                         // give up a staged copy (after it has landed)
         if (!staged.buf) return;
         (void)hipStreamSynchronize(c->copy_stream);
@@ -1136,7 +1139,8 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
         if (have) {
             f2q_timing one; memset(&one, 0, sizeof one);
             size_t cut = have;                     // only whole lines: a line is never split between blocks
-            if (!eof) while (cut > 0 && base[cut - 1] != 0x0a) cut--;
+            // (at the end of a damaged archive too: readline raised there instead of returning the cut-off line, :405-407)
+            if (!eof || src.truncated()) while (cut > 0 && base[cut - 1] != 0x0a) cut--;
             if (cut) {
                 if (mine.buf && carry.size() <= HEAD) {
                     const size_t c_len = carry.size(), textoff = HEAD - c_len, al = textoff & ~(size_t)15, lead = textoff - al;

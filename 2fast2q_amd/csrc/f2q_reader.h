@@ -10,7 +10,7 @@
 //          (slices + crc32_combine), header/trailer/multi-member handling is done here
 //
 // A BGZF file that turns into ordinary gzip half way (concatenated files) is continued as GZIP from that member.  A damaged or cut-off stream delivers the text before the damage and then
-// reports `truncated()` — the reference returns None for such a file (:580-582), the harness does the same.
+// reports `truncated()` — the reference keeps what it counted before the damage and warns (:405-407), the harness does the same.
 #pragma once
 #include <fcntl.h>
 #include <stdint.h>

@@ -107,9 +107,10 @@ def _counter_kwargs(param):
 
 
 def reads_counter(i, raw, features, param, reads_stats, preprocess=False):
-    """Counts one FASTQ(.gz) file (:514-582).  Returns (features, reads_stats, local_read_stats), or None
-    for a corrupted gzip -- the reference's contract.  `features` is updated in place: Counter mode adds
-    to Features.counts, Extract+Count mode adds the de-novo keys in first-occurrence order."""
+    """Counts one FASTQ(.gz) file (:514-582).  Returns (features, reads_stats, local_read_stats) -- the reference's
+    contract.  A cut-off or damaged .gz gives the counts of every complete record before the damage plus the
+    reference's warning (its parser keeps what it counted when readline raises, :405-407).  `features` is updated in
+    place: Counter mode adds to Features.counts, Extract+Count mode adds the de-novo keys in first-occurrence order."""
     if (param['upstream'] is not None) and (param['downstream'] is not None):
         if len(str(param['upstream']).split(",")) != len(str(param['downstream']).split(",")):
             colourful_errors("FATAL", "Up and Downstream sequences must be submitted in concurrent pairs, separated by ,.")
@@ -144,40 +145,64 @@ def reads_counter(i, raw, features, param, reads_stats, preprocess=False):
     return features, reads_stats, local_read_stats
 
 
+@dataclass
+class SampleResult:
+    """What one sample contributes to the run's tables: kept in memory from aligner() to compiling()
+    (the reference round-trips this through <sample>_reads.csv and an English sentence, :785-799, :1316-1406)."""
+    name: str            # file stem without .fastq / .gz (:779-783)
+    time_value: str      # "0.52" / "1.03" ...
+    time_unit: str       # seconds / minutes / hours
+    rows: list           # [feature name, reads] in the sample's row order (numeric or alphabetical, :790-793)
+    stats: dict          # the five counters of reads_counter (:310-316)
+
+    def sentence(self):
+        """first line of <sample>_reads.csv, as upstream words it (:785)"""
+        st = self.stats
+        return (f'#script ran in {self.time_value} {self.time_unit} for file {self.name}. '
+                f'{st["perfect_counter"] + st["imperfect_counter"]} reads out of {st["reads"]} were aligned. '
+                f'{st["perfect_counter"]} were perfectly aligned. '
+                f'{st["imperfect_counter"]} were aligned with mismatch. '
+                f'{st["non_aligned_counter"]} passed quality filtering but were not aligned. '
+                f'{st["quality_failed"]} did not pass quality filtering.')
+
+    def reads_csv_rows(self):
+        return [[self.sentence()], ["#Feature", "Reads"]] + [list(r) for r in self.rows]
+
+
+def _sample_name(raw):
+    name = Path(raw).stem
+    return Path(name).stem if ".fastq" in name else name
+
+
+def _elapsed_text(seconds):
+    """(value, unit) of aligner's running time (:771-777)"""
+    if seconds > 3600:
+        return str(round(seconds / 3600, 2)), "hours"
+    if seconds > 60:
+        return str(round(seconds / 60, 2)), "minutes"
+    return str(round(seconds, 2)), "seconds"
+
+
 def aligner(i, raw, features, param, reads_stats):
-    """one sample: count, then write <sample>_reads.csv (:752-801)"""
-    tempo = time.perf_counter()
+    """One sample (:752-801): count it, order its rows, and keep the result for compiling() in param["samples"].
+    <sample>_reads.csv is only written when the temporaries are kept (--k): nothing reads it back."""
+    started = time.perf_counter()
     packed = reads_counter(i, raw, features, param, reads_stats)
     if packed is None:
         return reads_stats
     features, reads_stats, local = packed
-    master_list = [[features[g].name, features[g].counts] for g in features]
-    tempo = time.perf_counter() - tempo
-    if tempo > 3600:
-        timing = str(round(tempo / 3600, 2)) + " hours"
-    elif tempo > 60:
-        timing = str(round(tempo / 60, 2)) + " minutes"
-    else:
-        timing = str(round(tempo, 2)) + " seconds"
-    name = Path(raw).stem
-    if ".fastq" in name:
-        name = Path(name).stem
-    stats_condition = (f'#script ran in {timing} for file {name}. '
-                       f'{local["perfect_counter"] + local["imperfect_counter"]} reads out of {local["reads"]} were aligned. '
-                       f'{local["perfect_counter"]} were perfectly aligned. '
-                       f'{local["imperfect_counter"]} were aligned with mismatch. '
-                       f'{local["non_aligned_counter"]} passed quality filtering but were not aligned. '
-                       f'{local["quality_failed"]} did not pass quality filtering.')
-    if not param['Progress bar']:
-        colourful_errors("INFO", f"Sample {name} was processed in {timing}")
+    rows = [[f.name, f.counts] for f in features.values()]
+    value, unit = _elapsed_text(time.perf_counter() - started)
     try:
-        master_list.sort(key=lambda row: int(row[0]))
+        rows.sort(key=lambda row: int(row[0]))       # all names numeric: numerical order
     except ValueError:
-        master_list.sort(key=lambda row: row[0])
-    master_list.insert(0, ["#Feature", "Reads"])
-    master_list.insert(0, [stats_condition])
-    if sharding.world().rank == 0:
-        csv_writer(os.path.join(param["directory"], name + "_reads.csv"), master_list)
+        rows.sort(key=lambda row: row[0])
+    sample = SampleResult(_sample_name(raw), value, unit, rows, dict(local))
+    if not param['Progress bar']:
+        colourful_errors("INFO", f"Sample {sample.name} was processed in {value} {unit}")
+    param.setdefault("samples", {})[sample.name] = sample     # a later file of the same name replaces the earlier one,
+    if not param.get("delete", True) and sharding.world().rank == 0:   # as its _reads.csv would upstream
+        csv_writer(os.path.join(param["directory"], sample.name + "_reads.csv"), sample.reads_csv_rows())
     return reads_stats
 
 
@@ -367,68 +392,90 @@ def aligner_mp_dispenser(features, param, start=0):
             one(i, raw)
 
 
-def compiling(param):
-    """merge the per-sample *_reads.csv into <name>.csv and the stats file (:1316-1384)"""
-    ordered_csv = path_parser(param["directory"], ['*reads.csv'])
-    headers = [f"#2FAST2Q version: {param['version']}",
-               f"#Mismatch: {param['miss']}",
-               f"#Phred Score: {param['phred']}",
-               f"#Feature Length: {param['length']}",
-               f"#Feature start position in the read: {param['start']}",
-               f"#Running mode: {param['Running Mode']}",
-               f"#Upstream search sequence: {param['upstream']}",
-               f"#Downstream search sequence: {param['downstream']}",
-               f"#Mismatches in the upstream search sequence: {param['miss_search_up']}",
-               f"#Mismatches in the downstream search sequence: {param['miss_search_down']}",
-               f"#Minimal Phred-score in the upstream search sequence: {param['qual_up']}",
-               f"#Minimal Phred-score in the downstream search sequence: {param['qual_down']}"]
+def _samples_from_directory(directory):
+    """SampleResults of the <sample>_reads.csv files of a directory (a run whose temporaries were kept, or made by the
+    reference itself): the file layout of aligner() read back, for callers that have no in-memory results."""
+    found = {}
+    for path in path_parser(directory, ['*reads.csv']):
+        name = Path(path).stem[:-len("_reads")]
+        with open(path, newline='') as handle:
+            table = list(csv.reader(handle))
+        words = table[0][0].split()
+        numbers = [w for w in words if w.isdigit()]        # aligned, reads, perfect, imperfect, non aligned, failed
+        stats = dict(zip(("reads", "perfect_counter", "imperfect_counter", "non_aligned_counter", "quality_failed"),
+                         (int(numbers[-5]), int(numbers[-4]), int(numbers[-3]), int(numbers[-2]), int(numbers[-1]))))
+        found[name] = SampleResult(name, words[3], words[4], [[r[0], int(r[1])] for r in table[2:]], stats)
+    return found
+
+
+def run_headers(param):
+    """the '#key: value' lines that open <name>_stats.csv (:1323-1337)"""
+    lines = [f"#2FAST2Q version: {param['version']}"]
     if "used_cmd" in param:
-        headers.insert(1, f"#cmd used: {param['used_cmd']}")
-    headers.reverse()
-    compiled, head = {}, ["#Feature"]
-    for i, file in enumerate(ordered_csv):
-        sample = Path(os.path.splitext(file)[0]).stem[:-len("_reads")]
-        head.append(sample)
-        with open(file) as current:
-            for line in current:
-                cols = line.rstrip().split(",")
-                if "#" not in cols[0]:
-                    if cols[0] in compiled:
-                        compiled[cols[0]] = compiled[cols[0]] + [int(cols[1])]
-                    else:
-                        compiled[cols[0]] = [0] * i + [int(cols[1])]
-                elif "#Feature" not in cols[0]:
-                    headers.append(cols[0][1:] + "\n")
-        for entry in compiled:                                       # zero back-fill (:1361-1364)
-            if len(compiled[entry]) < i + 1:
-                compiled[entry] = compiled[entry] + [0] * (i + 1 - len(compiled[entry]))
-    run_stats(headers, param, compiled, head)
-    final = [head] + [[feature] + compiled[feature] for feature in compiled]
-    csv_writer(os.path.join(param["directory"], f"{param['out_file_name']}.csv"), final)
+        lines.append(f"#cmd used: {param['used_cmd']}")
+    lines += [f"#Mismatch: {param['miss']}",
+              f"#Phred Score: {param['phred']}",
+              f"#Feature Length: {param['length']}",
+              f"#Feature start position in the read: {param['start']}",
+              f"#Running mode: {param['Running Mode']}",
+              f"#Upstream search sequence: {param['upstream']}",
+              f"#Downstream search sequence: {param['downstream']}",
+              f"#Mismatches in the upstream search sequence: {param['miss_search_up']}",
+              f"#Mismatches in the downstream search sequence: {param['miss_search_down']}",
+              f"#Minimal Phred-score in the upstream search sequence: {param['qual_up']}",
+              f"#Minimal Phred-score in the downstream search sequence: {param['qual_down']}"]
+    return lines
+
+
+def compile_table(samples):
+    """(head, {feature: [reads per sample]}) of the run (:1341-1364).  Samples in the order upstream meets their
+    <sample>_reads.csv files (sorted by that file name); features in first-met order, a feature a sample lacks counts 0
+    there (Extract+Count samples have different key sets).  A feature name holding '#' is left out of the table, as
+    upstream's line filter does (:1350)."""
+    ordered = sorted(samples.values(), key=lambda s: s.name + "_reads.csv")
+    table = {}
+    for column, sample in enumerate(ordered):
+        for name, reads in sample.rows:
+            name = str(name)
+            if "#" in name:
+                continue
+            table.setdefault(name, [0] * column).append(int(reads))
+        for counts in table.values():
+            counts.extend([0] * (column + 1 - len(counts)))
+    return ordered, ["#Feature"] + [s.name for s in ordered], table
+
+
+def compiling(param):
+    """<name>.csv and <name>_stats.csv (+ plots) from the samples aligner() collected (:1316-1384); without in-memory
+    results the <sample>_reads.csv files of the output directory are read instead."""
+    samples = param.get("samples") or _samples_from_directory(param["directory"])
+    ordered, head, table = compile_table(samples)
+    run_stats(run_headers(param), param, table, head, ordered)
+    csv_writer(os.path.join(param["directory"], f"{param['out_file_name']}.csv"),
+               [head] + [[feature] + counts for feature, counts in table.items()])
     if param["delete"]:
-        for file in ordered_csv:
-            os.remove(file)
+        for path in path_finder(param["directory"], ['*reads.csv']):
+            os.remove(path[0])
     colourful_errors("INFO", "Analysis successfully completed")
     print("\n If you find 2FAST2Q useful, please consider citing:\n Bravo AM, Typas A, Veening J. 2022. \n 2FAST2Q: a general-purpose sequence search and counting program for FASTQ files. PeerJ 10:e14041\n DOI: 10.7717/peerj.14041\n")
     if param["test_mode"]:
         colourful_errors("WARNING", "Test successful. 2FAST2Q is working as intended!\n")
 
 
-def run_stats(headers, param, compiled, head):
-    """<name>_stats.csv plus the four overview plots (:1386-1527)"""
-    global_stat = [["#Sample name", "Running Time", "Running Time unit", "Total number of reads in sample",
-                    "Total number of reads that were aligned", "Number of reads that were aligned without mismatches",
-                    "Number of reads that were aligned with mismatches",
-                    "Number of reads that passed quality filtering but were not aligned",
-                    'Number of reads that did not pass quality filtering.']]
-    offset = 1
-    for run in headers:
-        if "script ran" in run:
-            w = run.split()        # the stats sentence written by aligner(); token positions as upstream (:1403-1406)
-            global_stat.append([w[7][:-1], w[3], w[4], w[12], w[8], w[15], w[19], w[24], w[32]])
-        else:
-            global_stat.insert(0, [run])
-            offset += 1
+STATS_HEAD = ["#Sample name", "Running Time", "Running Time unit", "Total number of reads in sample",
+              "Total number of reads that were aligned", "Number of reads that were aligned without mismatches",
+              "Number of reads that were aligned with mismatches",
+              "Number of reads that passed quality filtering but were not aligned",
+              'Number of reads that did not pass quality filtering.']
+
+
+def run_stats(headers, param, compiled, head, ordered):
+    """<name>_stats.csv -- the run's '#key: value' lines, the column names, one row of numbers per sample (:1386-1412,
+    taken from the counters themselves) -- plus the four overview plots (:1414-1527)"""
+    rows = [[s.name, s.time_value, s.time_unit, s.stats["reads"], s.stats["perfect_counter"] + s.stats["imperfect_counter"],
+             s.stats["perfect_counter"], s.stats["imperfect_counter"], s.stats["non_aligned_counter"],
+             s.stats["quality_failed"]] for s in ordered]
+    global_stat = [[line] for line in headers] + [STATS_HEAD] + rows
     csv_writer(os.path.join(param["directory"], f"{param['out_file_name']}_stats.csv"), global_stat)
     try:
         import matplotlib
@@ -438,7 +485,6 @@ def run_stats(headers, param, compiled, head):
     except Exception as exc:                                     # plots are cosmetic; say so and go on
         colourful_errors("WARNING", f"matplotlib unavailable ({exc}); plots skipped")
         return
-    rows = global_stat[offset:]
     base = os.path.join(param["directory"], param['out_file_name'])
     labels = [r[0] for r in rows]
 

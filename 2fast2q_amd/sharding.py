@@ -130,9 +130,12 @@ def reduce_results(ctx, w):
             __cuda_array_interface__ = {"shape": (n64,), "typestr": "<i8", "data": (ptr, False), "version": 3}
         dev = torch.device("cuda", torch.cuda.current_device())
         acc = torch.as_tensor(_Arr(), device=dev)
-        torch.cuda.current_stream().synchronize()
-        dist.all_reduce(acc)                       # RCCL, in place on the library's accumulator
-        torch.cuda.synchronize()
+        # RCCL, in place on the library's accumulator and on the library's own stream: ordered after the counting
+        # kernels without any host synchronisation (f2q_counts_device_ptr does none)
+        stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+        with torch.cuda.stream(stream):
+            dist.all_reduce(acc)
+        stream.synchronize()
         counts, stats = ctx.read_counts()
     else:
         counts, stats = ctx.read_counts()

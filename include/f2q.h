@@ -125,8 +125,9 @@ int f2q_set_features(f2q_ctx *ctx, const char *seqs, const uint32_t *offs, uint3
 int f2q_count_block(f2q_ctx *ctx, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_timing *t);
 /* reads_counter's file half (fast2q.py:560-578): plain or .gz FASTQ by path (gzip by content; blocked gzip --
  * BGZF -- is inflated member-parallel).  The file is streamed in pieces by a reader thread while the device
- * frames, packs and counts.  F2Q_ETRUNCATED: the archive is cut off or damaged; what was readable before the
- * damage has been counted (the reference returns None for such a file, :580-582; the harness does too). */
+ * frames, packs and counts.  F2Q_ETRUNCATED: the archive is cut off or damaged; every complete line before the damage has
+ * been counted, as the reference does (its parser keeps what it counted when readline raises, fast2q.py:405-407, and
+ * reads_counter returns those partial counts with a warning; the cut-off last line is never seen).  The harness too. */
 int f2q_count_file(f2q_ctx *ctx, const char *path, f2q_timing *t);
 /* The same file counted by `world` processes, one per GPU (replaces the chunk pool of
  * single_file_reads_binner, fast2q.py:447-512): every rank streams the whole file -- the 4-line framing is
@@ -163,7 +164,8 @@ int f2q_reset_counts(f2q_ctx *ctx);
 /* Counter mode: counts[n_features] + stats[5] (device -> host, synchronises the stream). */
 int f2q_read_counts(f2q_ctx *ctx, int64_t *counts, int64_t stats[5]);
 /* Device address of the int64[n_features + 5] accumulator (counts then stats), so a caller can
- * all-reduce it in place over RCCL (torch.distributed) before reading it back. */
+ * all-reduce it in place over RCCL (torch.distributed) before reading it back.  No synchronisation is done here:
+ * work on the accumulator must be ordered after the context's stream (f2q_stream), e.g. by issuing it on that stream. */
 int f2q_counts_device_ptr(f2q_ctx *ctx, void **dptr, uint64_t *n_int64);
 /* The HIP stream (hipStream_t) all work of this context is launched on. */
 void *f2q_stream(f2q_ctx *ctx);

@@ -138,6 +138,97 @@ def test_compiling_formats(tmp_path):
     assert rows[-3][0] == "#Sample name" and any("#Mismatch: 1" in r[0] for r in rows)
 
 
+def _golden_compiling_cases():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "compiling_cases.json")) as f:
+        d = json.load(f)
+    return d["cases"], d["elapsed"]
+
+
+class _Clock:
+    """the scripted perf_counter tests/golden/make_golden_compiling.py gave the reference"""
+
+    def __init__(self, elapsed):
+        self.t, self.k, self.started, self.elapsed = 100.0, 0, False, elapsed
+
+    def __call__(self):
+        if not self.started:
+            self.started = True
+            return self.t
+        self.started = False
+        self.t += self.elapsed[self.k % len(self.elapsed)]
+        self.k += 1
+        return self.t
+
+
+def golden_param(case, directory, keep=False):
+    p = {"cmd": True, "big_file_split": False, "test_mode": False, "out_file_name": "compiled", "length": 20,
+         "Progress bar": True, "start": "0", "phred": 30, "miss": 1, "upstream": None, "downstream": None,
+         "miss_search_up": 0, "miss_search_down": 0, "qual_up": 30, "qual_down": 30, "Running Mode": "C",
+         "delete": not keep, "cpu": 1}
+    p.update(case["params"])
+    p["version"] = case["expected"]["version"]
+    p["directory"] = str(directory)
+    return p
+
+
+@pytest.mark.parametrize("keep", [False, True], ids=["in_memory", "keep_temporaries"])
+@pytest.mark.parametrize("case", _golden_compiling_cases()[0], ids=[c["name"] for c in _golden_compiling_cases()[0]])
+def test_output_contract_vs_reference(case, keep, tmp_path, monkeypatch):
+    """aligner() -> compiling() of the harness against the bytes the REFERENCE's aligner/compiling/run_stats wrote for
+    the same samples (tests/golden/compiling_cases.json): compiled.csv and compiled_stats.csv byte for byte, sample
+    order, numeric vs alphabetical row order, zero back-fill, and -- with --k -- the <sample>_reads.csv files.
+    reads_counter is replaced by the reference's own per-sample result here (no GPU); tests/test_gpu_cli.py runs the
+    same cases through the device."""
+    exp = case["expected"]
+    by_file = {s["file"]: s["rows"] for s in exp["samples"]}
+    stats_rows = {r[0]: r for r in csv.reader(exp["compiled_stats.csv"].splitlines()) if len(r) == 9 and not r[0].startswith("#")}
+
+    def fake_reads_counter(i, raw, features, param, reads_stats, preprocess=False):
+        name = fast2q._sample_name(raw)
+        r = stats_rows[name]
+        for fname, seq, n in by_file[os.path.basename(raw)]:
+            if seq in features:
+                features[seq].counts += n
+            else:
+                features[seq] = fast2q.Features(fname, n)
+        local = dict(zip(binding.STAT_NAMES, (int(r[3]), int(r[5]), int(r[6]), int(r[7]), int(r[8]))))
+        return features, reads_stats, local
+
+    monkeypatch.setattr(fast2q, "reads_counter", fake_reads_counter)
+    monkeypatch.setattr(fast2q.time, "perf_counter", _Clock(_golden_compiling_cases()[1]))
+    param = golden_param(case, tmp_path, keep)
+    lib = {}
+    if case["features"] is not None:
+        for name, seq in case["features"]:
+            lib.setdefault(seq.upper().replace(" ", ""), name)
+    for i, (fname, _) in enumerate(case["files"]):
+        per_sample = {s: fast2q.Features(n, 0) for s, n in lib.items()}
+        fast2q.aligner(i, str(tmp_path / "in" / fname), per_sample, param, {})
+    if keep:
+        for f, text in exp["reads_csv"].items():
+            assert (tmp_path / f).read_bytes().decode("latin-1") == text
+    else:
+        assert not [f for f in os.listdir(tmp_path) if f.endswith("_reads.csv")]      # no temporary files at all
+    fast2q.compiling(param)
+    assert (tmp_path / "compiled.csv").read_bytes().decode("latin-1") == exp["compiled.csv"]
+    assert (tmp_path / "compiled_stats.csv").read_bytes().decode("latin-1") == exp["compiled_stats.csv"]
+    left = sorted(os.listdir(tmp_path))
+    assert left == (sorted(exp["files_left"] + list(exp["reads_csv"])) if keep else exp["files_left"])
+
+
+def test_compiling_reads_a_directory_of_reads_csv(tmp_path):
+    """without in-memory results compiling() takes the <sample>_reads.csv files of the directory -- e.g. the ones the
+    reference itself wrote -- and produces the reference's bytes from them"""
+    case = _golden_compiling_cases()[0][2]                       # Extract+Count, different key sets per sample
+    for f, text in case["expected"]["reads_csv"].items():
+        (tmp_path / f).write_bytes(text.encode("latin-1"))
+    fast2q.compiling(golden_param(case, tmp_path))
+    assert (tmp_path / "compiled.csv").read_bytes().decode("latin-1") == case["expected"]["compiled.csv"]
+    assert (tmp_path / "compiled_stats.csv").read_bytes().decode("latin-1") == case["expected"]["compiled_stats.csv"]
+    assert sorted(os.listdir(tmp_path)) == case["expected"]["files_left"]
+
+
 def test_reference_golden_compiled_format():
     # the reference's own tests/compiled.csv pins the format only (its FASTQ is not redistributed):
     # header '#Feature,<sample>' then one 'name,count' row per unique feature, in library order

@@ -65,6 +65,23 @@ def test_truncated_gzip_partial_counts(tmp_path, capsys):
     assert "incomplete or corrupted gzip" in capsys.readouterr().out
 
 
+def test_cut_off_gzip_vs_reference(tmp_path, capsys):
+    """archives cut at several positions: counts and stats must be what the reference's reads_counter returned for the
+    same bytes (tests/golden/truncated_gzip_cases.json) -- the cut-off last line is not a line"""
+    import base64
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "truncated_gzip_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        path = tmp_path / f"cut_{c['level']}_{c['frac']}.fastq.gz"
+        path.write_bytes(base64.b64decode(c["gz_b64"]))
+        features = {seq: fast2q.Features(name, 0) for name, seq in c["features"]}
+        feats, _, stats = fast2q.reads_counter(0, str(path), features, default_param(), {})
+        assert [f.counts for f in feats.values()] == c["expected"]["counts"], (c["level"], c["frac"])
+        assert [stats[k] for k in fast2q.binding.STAT_NAMES] == c["expected"]["stats"]
+        assert "incomplete or corrupted gzip" in capsys.readouterr().out
+
+
 def test_empty_and_tiny_files(tmp_path):
     """files with nothing / less than one record / one record without a final newline: the reader thread, the carry
     and the end-of-file piece of f2q_count_file"""
@@ -120,6 +137,39 @@ def test_count_file_shard_sums_to_the_whole(tmp_path, monkeypatch, kind, world):
             assert tot_counts == orc.counts()
         else:
             assert [(k, n) for k, n, _ in sharding.merge_ec_tables(tables)] == list(zip(orc.keys(), orc.counts()))
+
+
+def _output_cases():
+    from test_abi_and_host import _golden_compiling_cases
+    return _golden_compiling_cases()[0]
+
+
+@pytest.mark.parametrize("case", _output_cases(), ids=[c["name"] for c in _output_cases()])
+def test_output_contract_through_the_device(case, tmp_path, monkeypatch):
+    """the multi-sample runs of tests/golden/compiling_cases.json -- made by running the reference's aligner + compiling --
+    through aligner() -> reads_counter() -> libf2q_hip.so -> compiling(): compiled.csv and compiled_stats.csv must
+    be the reference's bytes (only the clock is scripted, as it was for the reference)"""
+    from test_abi_and_host import _Clock, _golden_compiling_cases, golden_param
+    exp = case["expected"]
+    indir = tmp_path / "in"
+    out = tmp_path / "out"
+    indir.mkdir(); out.mkdir()
+    for fname, text in case["files"]:
+        data = text.encode("latin-1")
+        (indir / fname).write_bytes(gzip.compress(data) if fname.endswith(".gz") else data)
+    param = golden_param(case, out)
+    lib = {}
+    if case["features"] is not None:
+        for name, seq in case["features"]:
+            lib.setdefault(seq.upper().replace(" ", ""), name)
+    monkeypatch.setattr(fast2q.time, "perf_counter", _Clock(_golden_compiling_cases()[1]))
+    for i, (fname, _) in enumerate(case["files"]):
+        per_sample = {s: fast2q.Features(n, 0) for s, n in lib.items()}
+        fast2q.aligner(i, str(indir / fname), per_sample, param, {})
+    fast2q.compiling(param)
+    assert (out / "compiled.csv").read_bytes().decode("latin-1") == exp["compiled.csv"]
+    assert (out / "compiled_stats.csv").read_bytes().decode("latin-1") == exp["compiled_stats.csv"]
+    assert sorted(os.listdir(out)) == exp["files_left"]
 
 
 def test_cli_test_mode_end_to_end(tmp_path, monkeypatch):

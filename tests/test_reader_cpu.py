@@ -182,3 +182,21 @@ def test_crc32_slicing_matches_zlib():
             assert lib().emu_crc32(0, d, len(d)) == (zlib.crc32(d) & 0xFFFFFFFF)
             half = len(d) // 3
             assert lib().emu_crc32(lib().emu_crc32(0, d[:half], half), d[half:], len(d) - half) == (zlib.crc32(d) & 0xFFFFFFFF)
+
+
+def test_cut_off_gzip_delivers_what_the_reference_reads(tmp_path):
+    """tests/golden/truncated_gzip_cases.json: archives cut at several positions and what the REFERENCE counted from them
+    (it keeps every complete record before readline raises, fast2q.py:405-407).  The product's reader must deliver
+    exactly as many complete records before reporting the damage."""
+    import base64
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "truncated_gzip_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 8
+    for c in cases:
+        path = tmp_path / f"cut_{c['level']}_{c['frac']}.fastq.gz"
+        path.write_bytes(base64.b64decode(c["gz_b64"]))
+        for piece in (1 << 12, 1 << 20):
+            text, truncated, kind = read_file(str(path), piece=piece)
+            assert truncated and kind == "gzip"
+            assert text.count(b"\n") // 4 == c["expected"]["stats"][0], (c["level"], c["frac"], piece)
