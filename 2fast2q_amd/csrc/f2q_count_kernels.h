@@ -301,6 +301,192 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     }
 }
 
+// ---- multi-window runs (--st a,b[,c,d]) on the packed path -----------------------------------------------------
+// The tile walk of k_count_fixed4 with the windows taken one after another: for each window the rows under it, the
+// Phred verdict of the four reads of the lane and the 2-bit part; a read's key is the concatenation of the parts that
+// passed, in window order, and is looked up among the features with that many parts (LibDev::mpk[k - 1]; the ':'
+// between the parts is implied by k, fast2q.py:349-363).  No part passed = quality failed (:389-390).  Exact probes per
+// part count k, misses queued per wave (the key's two top bits carry k - 1) and searched 64 at a time; reads that end
+// inside a window take the byte-exact routine on a copy rebuilt from the tile.
+__device__ __noinline__ void multi_slow(const RunDev *run, const LibDev *lib, const Accum *acc, const PackedBlock *pb,
+                                        uint32_t tile, uint32_t slot, int r, unsigned long long *st)
+{
+    uint8_t seq[F2Q_ANCHOR_MAXLEN], qual[F2Q_ANCHOR_MAXLEN];
+    const auto bp = gp(pb->bases) + (uint64_t)tile * pb->wb * F2Q_TILE + slot;
+    const auto qp = gp(pb->qual) + (uint64_t)tile * pb->wq * F2Q_TILE + slot;
+    if (r > F2Q_ANCHOR_MAXLEN) r = F2Q_ANCHOR_MAXLEN;
+    for (int i = 0; i < r; i++) {
+        seq[i] = (uint8_t)"ACGT"[(bp[(uint64_t)(i >> 4) * F2Q_TILE] >> (2 * (i & 15))) & 3u];
+        qual[i] = (uint8_t)((qp[(uint64_t)(i >> 2) * F2Q_TILE] >> (8 * (i & 3))) & 0xFFu);
+        if (qual[i] & 0x80u) { seq[i] = (uint8_t)'N'; qual[i] &= 0x7Fu; }      // flagged: a symbol that equals nothing
+    }
+    const EcDev none{};
+    general_read<const uint8_t *>(*run, *lib, none, *acc, seq, r, qual, r, 0ull, st);
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_multi4(const RunDev *__restrict__ runp,
+                                                                  const LibDev *__restrict__ libp, PackedBlock pb,
+                                                                  Accum acc, int need)
+{
+    extern __shared__ unsigned long long smem64[];
+    unsigned long long *queue = smem64 + (threadIdx.x >> 6) * F2Q_V2_QCAP;                 // keys | (k - 1) << 62
+    uint32_t *qforced = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + (threadIdx.x >> 6) * F2Q_V2_QCAP;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem64 + F2Q_V2_WAVES * F2Q_V2_QCAP) + F2Q_V2_WAVES * F2Q_V2_QCAP;  // USE_LDS
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (USE_LDS) for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) hist[i] = 0;
+    __syncthreads();
+    uint32_t q_head = 0, q_tail = 0;
+    const int W = run.n_iter, L = run.length;
+    const bool do_near = run.miss > 0;
+    const auto ptab = gp(lib.ptab);
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    auto count_hit = [&](uint32_t idx) {
+        if (USE_LDS) atomicAdd(&hist[idx], 1u);
+        else acc_add(&acc.counts[idx], 1ull);
+    };
+    auto drain = [&](bool all) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t tail = q_tail;
+        while (all ? (tail != q_head) : (tail - q_head >= 64u)) {
+            if (lane < tail - q_head) {
+                const unsigned long long e = queue[(q_head + lane) % F2Q_V2_QCAP];
+                uint32_t idx = 0;
+                const int r = packed_near_decide(run, lib, lib.mpk[(uint32_t)(e >> 62)], e & ((1ull << 62) - 1ull),
+                                                 qforced[(q_head + lane) % F2Q_V2_QCAP], idx);
+                if (r == R_IMPERFECT || r == R_PERFECT) { count_hit(idx); st[2]++; } else st[3]++;
+            }
+            q_head += (tail - q_head < 64u) ? (tail - q_head) : 64u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    for (uint32_t base = blockIdx.x * F2Q_V2_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_V2_WAVES) {
+        const uint32_t tile = base + wave;
+        if (tile < pb.n_tiles) {
+            int res[4]; uint64_t key[4] = {0, 0, 0, 0}; uint32_t forced[4] = {0, 0, 0, 0}, npart[4] = {0, 0, 0, 0}, lv[4];
+            {
+                typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+                v2 len2 = {pb.rmax | (pb.rmax << 16), pb.rmax | (pb.rmax << 16)};
+                if (pb.len) len2 = *(const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)tile * F2Q_TILE + 4u * lane);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    lv[j] = ((j < 2 ? len2.x : len2.y) >> (16 * (j & 1))) & 0xFFFFu;
+                    res[j] = lv[j] == F2Q_LEN_SKIP ? R_SKIP : ((int)(lv[j] & 0x7FFFu) < need) ? R_SLOW : R_NEAR;
+                }
+            }
+            const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane;
+            const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane;
+            for (int w = 0; w < W; w++) {
+                const FixedGeom g = fixed_geom_of(run, w);
+                U4 brow[F2Q_MAXBROWS], qrow[F2Q_MAXQROWS];
+#pragma unroll
+                for (int r = 0; r < F2Q_MAXBROWS; r++) {
+                    uint32_t row = (uint32_t)g.bw0 + (uint32_t)(r < g.nb ? r : g.nb - 1);
+                    row = row < pb.wb ? row : pb.wb - 1u;       // blocks whose reads all end before this window
+                    brow[r] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
+                }
+#pragma unroll
+                for (int r = 0; r < F2Q_MAXQROWS; r++) {
+                    uint32_t row = (uint32_t)g.qw0 + (uint32_t)(r < g.nq ? r : g.nq - 1);
+                    row = row < pb.wq ? row : pb.wq - 1u;
+                    qrow[r] = ld_u4<true>(qp + (uint64_t)row * F2Q_TILE);
+                }
+                uint32_t bad[4] = {0, 0, 0, 0};
+                if (g.add_hi) {
+#pragma unroll
+                    for (int r = 0; r < F2Q_MAXQROWS; r++)
+                        if (r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (res[j] != R_NEAR || bad[j]) continue;          // this part fails its Phred test: omitted (:357-360)
+                    key[j] |= fixed4_key(g, brow, j) << (2u * (uint32_t)L * npart[j]);
+                    if (lv[j] & F2Q_LEN_FLAG) forced[j] |= fixed4_flags(g, qrow, j) << ((uint32_t)L * npart[j]);
+                    npart[j]++;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (res[j] == R_SLOW) {
+                    unsigned long long st2[5] = {0, 0, 0, 0, 0};
+                    const Accum acc2 = acc; const PackedBlock pb2 = pb;
+                    multi_slow(runp, libp, &acc2, &pb2, tile, 4u * lane + (uint32_t)j, (int)(lv[j] & 0x7FFFu), st2);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) st[k] += st2[k];
+                    res[j] = R_SKIP;                                   // counted by the routine itself
+                } else if (res[j] == R_NEAR) {
+                    st[0]++;
+                    if (npart[j] == 0u) { res[j] = R_QFAIL; st[4]++; }
+                    else if (forced[j]) res[j] = (!do_near || __popc(forced[j]) > run.miss) ? R_NONALIGNED : R_FORCED;
+                }
+            }
+            // exact probes, one part count at a time (almost every read has all W parts)
+            for (int k = W; k >= 1; k--) {
+                bool mine[4]; bool any = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { mine[j] = res[j] == R_NEAR && npart[j] == (uint32_t)k; any |= mine[j]; }
+                if (__ballot(any) == 0ull) continue;
+                const PackedGroup &pk = lib.mpk[k - 1];
+                const PackedPiece ex = pk.exact;
+                const uint32_t ib = pk.ib, exm = (1u << ex.bits) - 1u;
+                const uint64_t imask = (1ull << ib) - 1ull;
+                if (pk.len == 0u) continue;                           // no feature has k parts: nothing to hit (misses stay R_NEAR)
+                uint32_t s[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[j] = hash32(key[j], ex.bits);
+                while (mine[0] | mine[1] | mine[2] | mine[3]) {
+                    uint64_t v0[4], v1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (mine[j]) { v0[j] = ptab[ex.off + s[j]]; v1[j] = ptab[ex.off + ((s[j] + 1u) & exm)]; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (!mine[j]) continue;
+                        if (v0[j] == KEY_EMPTY) mine[j] = false;
+                        else if ((v0[j] >> ib) == key[j]) { mine[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v0[j] & imask)); }
+                        else if (v1[j] == KEY_EMPTY) mine[j] = false;
+                        else if ((v1[j] >> ib) == key[j]) { mine[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v1[j] & imask)); }
+                        else s[j] = (s[j] + 2u) & exm;
+                    }
+                }
+            }
+            uint32_t npush = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (res[j] == R_NEAR) { if (do_near) npush++; else res[j] = R_NONALIGNED; }
+                else if (res[j] == R_FORCED) npush++;
+                st[1] += (res[j] == R_PERFECT); st[3] += (res[j] == R_NONALIGNED);
+            }
+            {
+                const unsigned long long b0 = __ballot(npush & 1u), b1 = __ballot(npush & 2u), b2 = __ballot(npush & 4u);
+                uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))
+                              + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u))
+                              + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+                q_tail += (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (res[j] == R_NEAR || res[j] == R_FORCED) {
+                        queue[at % F2Q_V2_QCAP] = key[j] | ((unsigned long long)(npart[j] - 1u) << 62);
+                        qforced[at % F2Q_V2_QCAP] = forced[j];
+                        at++;
+                    }
+            }
+        }
+        if (do_near) drain(false);
+    }
+    if (do_near) drain(true);
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, acc.stat_slab ? acc.stat_slab + (uint64_t)blockIdx.x * 8u : nullptr);
+    if (USE_LDS) {
+        __syncthreads();
+        auto row = gpw(acc.slab) + (uint64_t)blockIdx.x * nf;
+        for (uint32_t i = tid; i < nf; i += F2Q_V2_THREADS) row[i] = hist[i];
+    }
+}
+
 // ---- fast path v3: the library in LDS ------------------------------------------------------------------
 // Fixed-offset Counter mode for uniform libraries of 14..21-base features searched with --m <= 1 (the reference's
 // default, and BASELINE configs 2 and 3): the tile walk of k_count_fixed4, but every lookup -- exact hit and the

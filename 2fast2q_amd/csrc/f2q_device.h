@@ -94,10 +94,15 @@ struct LtDesc {
     const uint32_t *feat_of;           // [F2Q_LT_SLOTS] feature of a table-0 slot (unused slots: 0)
 };
 
+// multi-window runs (--st a,b,...): a key is the ':'-joined windows that passed their Phred test (fast2q.py:349-363);
+// features made of k ACGT runs of --l bases joined by ':' ("k-part features") are indexed by their k*l bases
+#define F2Q_MW_MAX 4               // windows of a run the packed path handles (k * l <= 31 bases)
 struct LibDev {
     uint32_t n_features, n_irregular;
     const uint64_t *ptab;              // packed slots (KEY_EMPTY = free)
     PackedGroup pk;
+    PackedGroup mpk[F2Q_MW_MAX];       // multi-window runs: packed tables of the k-part features, k = index + 1 (len = k * l)
+    uint32_t mw_ok, mw_pad;            // 1: every feature a multi-window key can equal or approach is a k-part feature
     LtDesc lt;
     const uint64_t *tab_keys;          // open-addressing slots: 2-bit feature key or KEY_EMPTY
     const uint32_t *tab_idx;           // feature index of the slot
@@ -742,10 +747,10 @@ struct FixedGeom {
     uint64_t kmask;            // (1 << 2L) - 1
 };
 
-F2Q_HD FixedGeom fixed_geom(const RunDev &run)
+F2Q_HD FixedGeom fixed_geom_at(int st, int L, int thr)
 {
     FixedGeom g;
-    g.st = run.start[0]; g.L = run.length;
+    g.st = st; g.L = L;
     const int a = g.st, b = g.st + g.L;
     g.qw0 = a >> 2; g.nq = g.L > 0 ? ((b - 1) >> 2) - g.qw0 + 1 : 0;
     g.bw0 = a >> 4; g.nb = g.L > 0 ? ((b - 1) >> 4) - g.bw0 + 1 : 0;
@@ -753,11 +758,12 @@ F2Q_HD FixedGeom fixed_geom(const RunDev &run)
     g.qm_last = g.L > 0 ? (0x80808080u & (0xFFFFFFFFu >> (8 * (3 - ((b - 1) & 3))))) : 0u;
     if (g.nq == 1) { g.qm_first &= g.qm_last; g.qm_last = g.qm_first; }
     g.add_lo = 0x5F5F5F5Fu;
-    g.add_hi = run.thr >= 33 ? (uint32_t)(127 - run.thr) * 0x01010101u : 0u;
+    g.add_hi = thr >= 33 ? (uint32_t)(127 - thr) * 0x01010101u : 0u;
     g.sh = 2 * (a & 15);
     g.kmask = g.L >= 32 ? ~0ull : ((1ull << (2 * g.L)) - 1ull);
     return g;
 }
+F2Q_HD FixedGeom fixed_geom(const RunDev &run) { return fixed_geom_at(run.start[0], run.length, run.thr); }
 
 // result codes of one read in the v2 kernel
 enum { R_SKIP = 0, R_PERFECT = 1, R_IMPERFECT = 2, R_NONALIGNED = 3, R_QFAIL = 4, R_SLOW = 5, R_NEAR = 6, R_FORCED = 7 };
@@ -786,10 +792,10 @@ F2Q_HD uint64_t fixed4_key(const FixedGeom &g, const U4 (&b)[BR], int j)
 }
 
 // exact probe of the packed table: feature index or -1.  Two slots are fetched per round.
-F2Q_HD int packed_exact(const LibDev &lib, uint64_t key)
+F2Q_HD int packed_exact(const LibDev &lib, const PackedGroup &pk, uint64_t key)
 {
-    const PackedPiece &e = lib.pk.exact;
-    const uint32_t m = (1u << e.bits) - 1u, ib = lib.pk.ib;
+    const PackedPiece &e = pk.exact;
+    const uint32_t m = (1u << e.bits) - 1u, ib = pk.ib;
     uint32_t s = hash32(key, e.bits);
     const auto ptab = gp(lib.ptab);
     for (;;) {
@@ -801,6 +807,7 @@ F2Q_HD int packed_exact(const LibDev &lib, uint64_t key)
         s = (s + 2) & m;
     }
 }
+F2Q_HD int packed_exact(const LibDev &lib, uint64_t key) { return packed_exact(lib, lib.pk, key); }
 
 // bit i -> bit 2i
 F2Q_HD uint64_t spread32(uint32_t v)
@@ -833,19 +840,19 @@ F2Q_HD uint32_t fixed4_flags(const FixedGeom &g, const U4 (&q)[QR], int j)
 // pigeonhole search on the packed piece tables; forced2 = 2-bit-spaced mask of query positions that
 // mismatch every feature (non-ACGT symbols).  The first slot of every piece's chain (up to 4 pieces) is
 // fetched before any chain is walked, so the usual m = 1 lookup costs one memory round trip, not two.
-F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTrack &t)
+F2Q_HD void packed_near(const LibDev &lib, const PackedGroup &pk, uint64_t key, uint64_t forced2, MinTrack &t)
 {
-    const uint32_t ib = lib.pk.ib;
+    const uint32_t ib = pk.ib;
     const uint64_t imask = (1ull << ib) - 1ull;
     const auto ptab = gp(lib.ptab);
     const int nforced = popc64(forced2);
     const uint64_t keep = ~(forced2 | (forced2 << 1));
-    const uint32_t np = lib.pk.n_pieces;
+    const uint32_t np = pk.n_pieces;
     uint32_t s0[4]; uint64_t v0[4], v1[4];
 #pragma unroll
     for (uint32_t p = 0; p < 4; p++) {
         if (p < np) {
-            const PackedPiece pd = lib.pk.piece[p];
+            const PackedPiece pd = pk.piece[p];
             s0[p] = hash32((key >> pd.shift) & pd.mask, pd.bits);
             v0[p] = ptab[pd.off + s0[p]];                                   // the chain's first two slots: at load
             v1[p] = ptab[pd.off + ((s0[p] + 1u) & ((1u << pd.bits) - 1u))];  // factor <= 0.25 most chains end here
@@ -854,7 +861,7 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
 #pragma unroll
     for (uint32_t p = 0; p < F2Q_MAX_PIECES; p++) {
         if (p >= np) break;
-        const PackedPiece pd = lib.pk.piece[p];
+        const PackedPiece pd = pk.piece[p];
         if ((forced2 >> pd.shift) & pd.mask) continue;                       // this piece can never agree
         const uint32_t m = (1u << pd.bits) - 1u;
         uint32_t s = p < 4 ? s0[p < 4 ? p : 0] : hash32((key >> pd.shift) & pd.mask, pd.bits);
@@ -867,7 +874,7 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
             if (((x >> pd.shift) & pd.mask) == 0) {
                 bool dup = false;
                 for (uint32_t q = 0; q < p; q++) {
-                    const PackedPiece qd = lib.pk.piece[q];
+                    const PackedPiece qd = pk.piece[q];
                     if ((forced2 >> qd.shift) & qd.mask) continue;
                     if (((x >> qd.shift) & qd.mask) == 0) { dup = true; break; }
                 }
@@ -882,13 +889,25 @@ F2Q_HD void packed_near(const LibDev &lib, uint64_t key, uint64_t forced2, MinTr
 
 // decision for a key whose exact probe missed, or that holds flagged symbols (one bit per base in
 // `forced`): the work the v2 kernel queues and compacts
-F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key, uint32_t forced, uint32_t &idx)
+F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, const PackedGroup &pk, uint64_t key, uint32_t forced, uint32_t &idx)
 {
     MinTrack t; t.init(run.miss);
-    packed_near(lib, key, forced ? spread32(forced) : 0ull, t);
+    packed_near(lib, pk, key, forced ? spread32(forced) : 0ull, t);
     if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? R_PERFECT : R_IMPERFECT; }
     return R_NONALIGNED;
 }
+F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key, uint32_t forced, uint32_t &idx)
+{
+    return packed_near_decide(run, lib, lib.pk, key, forced, idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-window runs on the packed path (--st a,b[,c,d] --l n, Counter mode, k * n <= 31): for every window the Phred
+// test and the 2-bit part; the parts that passed are concatenated in window order (the ':' between them is implied by
+// the part count k, fast2q.py:349-363) and looked up among the k-part features.  One lane = 4 reads, windows one after
+// another.  geometry of window w = that of a single-window run starting at run.start[w].
+// ---------------------------------------------------------------------------------------------
+F2Q_HD FixedGeom fixed_geom_of(const RunDev &run, int w) { return fixed_geom_at(run.start[w], run.length, run.thr); }
 
 // ---------------------------------------------------------------------------------------------
 // LDS tables: the whole library inside the workgroup's LDS (north star: "the feature table tiled into LDS").
@@ -1383,7 +1402,8 @@ F2Q_HD uint64_t plane_key(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], in
 #define F2Q_ANCHOR_MAXLEN 160      // longest read the packed anchored kernel holds in registers (5 x 32 bases)
 
 struct PackPlan {
-    bool fast_fixed = false;       // fixed offset, one window, 0 <= length <= 31, Counter mode
+    bool fast_fixed = false;       // fixed offset, one window of 0..31 bases (Counter mode; Extract+Count: 0..29), or `multi`
+    bool multi = false;            // fixed offset, 2..4 windows of n bases each, k * n <= 31, Counter mode
     int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
     int from = 0;                  // ... and only [from, need) is ever looked at
     bool inband_n = false;         // non-ACGT symbols travel as flag bits (all-ACGT library only)

@@ -24,6 +24,8 @@ struct HostIndex {
     std::vector<uint64_t> key2;          // 2-bit key per feature (0 for irregular ones)
     std::vector<uint64_t> ptab;          // packed slots of the run's feature length (v2 fast kernel)
     PackedGroup pk;
+    PackedGroup mpk[F2Q_MW_MAX];         // multi-window runs: tables of the k-part features (index k - 1)
+    uint32_t mw_ok = 0;
     // LDS tables (f2q_device.h: LtDesc); lt.ok == 0: not applicable / the cuckoo build failed
     LtDesc lt{};
     std::vector<uint32_t> lt_tags, lt_feat_of;
@@ -66,12 +68,13 @@ inline void packed_insert(std::vector<uint64_t> &tab, const PackedPiece &pd, uin
     tab[pd.off + s] = slot;
 }
 
-// packed tables for features of length `len` (the window length of a fixed-offset run): built when
-// key bits + index bits fit one u64 and the pigeonhole pieces are regular
-inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int len, int miss)
+// packed tables for features of `len` bases (the window length of a fixed-offset run; k windows' worth for the k-part
+// features of a multi-window run): built when key bits + index bits fit one u64 and the pigeonhole pieces are
+// regular.  The tables are appended to ix.ptab.
+inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int len, int miss, PackedGroup &g)
 {
-    memset(&ix.pk, 0, sizeof ix.pk);
-    ix.ptab.assign(1, KEY_EMPTY);
+    memset(&g, 0, sizeof g);
+    if (ix.ptab.empty()) ix.ptab.assign(1, KEY_EMPTY);
     if (len < 1 || len > F2Q_REG_MAXLEN || ids.empty()) return;
     uint32_t ib = 1;
     while ((1ull << ib) < (uint64_t)ix.n_features + 1) ib++;
@@ -80,9 +83,8 @@ inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int le
     if (P > len || P > F2Q_MAX_PIECES) return;
     const uint32_t bits = table_bits((uint32_t)ids.size()) + 1;          // load factor <= 0.25
     if (bits > 30) return;
-    PackedGroup &g = ix.pk;
     g.len = (uint32_t)len; g.ib = ib; g.n_pieces = (uint32_t)P;
-    uint32_t off = 0;
+    uint32_t off = (uint32_t)ix.ptab.size();
     g.exact.off = off; g.exact.bits = bits; g.exact.shift = 0; g.exact.mask = ~0ull; off += 1u << bits;
     for (int p = 0; p < P; p++) {
         int b0 = (int)((long)p * len / P), b1 = (int)((long)(p + 1) * len / P);
@@ -90,12 +92,31 @@ inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int le
         g.piece[p].shift = (uint32_t)(2 * b0);
         g.piece[p].mask = (b1 - b0 >= 32) ? ~0ull : ((1ull << (2 * (b1 - b0))) - 1ull);
     }
-    ix.ptab.assign(off, KEY_EMPTY);
+    ix.ptab.resize(off, KEY_EMPTY);
     for (uint32_t f : ids) {
         const uint64_t k = ix.key2[f], slot = (k << ib) | f;
         packed_insert(ix.ptab, g.exact, k, slot);
         for (int p = 0; p < P; p++) packed_insert(ix.ptab, g.piece[p], (k >> g.piece[p].shift) & g.piece[p].mask, slot);
     }
+}
+
+// a k-part feature of a multi-window run: k runs of exactly `l` ACGT symbols joined by ':' (what the ':'-joined
+// windows of a read look like, fast2q.py:358-363); key = the k*l bases, 2 bits each
+inline int parts_key(const uint8_t *s, uint32_t n, int l, int max_parts, uint64_t &key)
+{
+    if (l < 1 || (n + 1) % (uint32_t)(l + 1) != 0) return 0;
+    const int k = (int)((n + 1) / (uint32_t)(l + 1));
+    if (k < 2 || k > max_parts || k * l > F2Q_REG_MAXLEN) return 0;
+    key = 0;
+    int b = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        const bool sep = (j % (uint32_t)(l + 1)) == (uint32_t)l;
+        if (sep) { if (s[j] != (uint8_t)':') return 0; continue; }
+        const uint32_t c = base_code(s[j]);
+        if (c > 3u) return 0;
+        key |= (uint64_t)c << (2 * b++);
+    }
+    return k;
 }
 
 // LDS tables for a library whose features all have the window length (f2q_device.h, "LDS tables").  Cuckoo
@@ -156,7 +177,9 @@ inline void build_lt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, i
     ix.lt = lt;
 }
 
-inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss, int packed_len = 0)
+// packed_len: the feature length the packed tables index (the window length of a fixed-offset run); mw_windows >= 2:
+// a multi-window run of that many windows, whose k-part features get packed tables of their own
+inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss, int packed_len = 0, int mw_windows = 0)
 {
     ix = HostIndex();
     ix.n_features = n;
@@ -168,11 +191,21 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
     ix.key2.assign(n, 0);
     memset(ix.grp, 0, sizeof ix.grp);
     std::vector<std::vector<uint32_t>> by_len(F2Q_REG_MAXLEN + 1);
+    std::vector<std::vector<uint32_t>> by_parts(F2Q_MW_MAX + 1);          // multi-window runs: k-part features, k >= 2
+    const bool multi = mw_windows >= 2 && mw_windows <= F2Q_MW_MAX && packed_len >= 1;
+    bool mw_ok = multi;
     for (uint32_t f = 0; f < n; f++) {
         uint32_t len = ix.feat_off[f + 1] - ix.feat_off[f];
         uint64_t k;
-        if (feature_key(ix.feat_bytes.data() + ix.feat_off[f], len, k)) { ix.key2[f] = k; by_len[len].push_back(f); }
-        else ix.irr_ids.push_back(f);
+        int parts;
+        if (feature_key(ix.feat_bytes.data() + ix.feat_off[f], len, k)) {
+            ix.key2[f] = k; by_len[len].push_back(f);
+            // a plain feature as long as a joined key of k >= 2 parts could be within --m of such a key (the ':' being
+            // one of the mismatches): the packed multi-window tables would not see it
+            if (multi) for (int q = 2; q <= mw_windows; q++) if ((int)len == q * packed_len + q - 1) mw_ok = false;
+        } else if (multi && (parts = parts_key(ix.feat_bytes.data() + ix.feat_off[f], len, packed_len, mw_windows, k)) != 0) {
+            ix.key2[f] = k; by_parts[parts].push_back(f);
+        } else ix.irr_ids.push_back(f);
     }
     uint32_t off = 0;
     for (int L = 1; L <= F2Q_REG_MAXLEN; L++) {
@@ -209,8 +242,20 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
                 table_insert(ix.tab_keys, ix.tab_idx, g.piece[p], (k >> g.piece[p].shift) & g.piece[p].mask, k, f);
         }
     }
+    ix.ptab.clear();
     build_packed(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(),
-                 packed_len, miss);
+                 packed_len, miss, ix.pk);
+    for (auto &g : ix.mpk) memset(&g, 0, sizeof g);
+    ix.mw_ok = 0;
+    if (multi) {
+        ix.mpk[0] = ix.pk;
+        for (int q = 2; q <= mw_windows; q++) {
+            build_packed(ix, by_parts[q], q * packed_len, miss, ix.mpk[q - 1]);
+            if (!by_parts[q].empty() && ix.mpk[q - 1].len == 0) mw_ok = false;      // tables could not be built
+        }
+        if (!by_len[packed_len].empty() && ix.pk.len == 0) mw_ok = false;
+        ix.mw_ok = mw_ok ? 1u : 0u;
+    }
     build_lt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss);
     ix.n_irregular = (uint32_t)ix.irr_ids.size();
     if (ix.irr_ids.empty()) ix.irr_ids.push_back(0);     // keep the device array non-empty
@@ -257,6 +302,13 @@ inline PackPlan make_plan(const RunDev &run)
                     run.start[0] + run.length <= F2Q_PACK_MAXLEN;
     pl.need = pl.fast_fixed ? run.start[0] + run.length : 0;
     pl.from = pl.fast_fixed ? run.start[0] : 0;
+    // several windows (--st a,b,...): Counter mode, every window inside the packed range, all parts in one 2-bit key
+    if (run.fixed && run.mode == 0 && run.n_iter >= 2 && run.n_iter <= F2Q_MW_MAX && run.length >= 1 &&
+        run.n_iter * run.length <= F2Q_REG_MAXLEN) {
+        int lo = run.start[0], hi = run.start[0];
+        for (int i = 1; i < run.n_iter; i++) { lo = run.start[i] < lo ? run.start[i] : lo; hi = run.start[i] > hi ? run.start[i] : hi; }
+        if (lo >= 0 && hi + run.length <= F2Q_PACK_MAXLEN) { pl.fast_fixed = true; pl.multi = true; pl.from = lo; pl.need = hi + run.length; }
+    }
     pl.fast_anchor = !run.fixed && run.n_iter == 1 && run.anchors_packed && run.msu >= 0 && run.msd >= 0 &&
                      run.msu <= 7 && run.msd <= 7 && run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN;
     pl.kb = (run.msu == 0 && run.msd == 0) ? 0 : (run.msu <= 1 && run.msd <= 1) ? 1 : 3;

@@ -209,6 +209,8 @@ static int upload_lib(f2q_ctx *c)
     L.n_irregular = c->ix.n_irregular;
     memcpy(L.grp, c->ix.grp, sizeof L.grp);
     L.pk = c->ix.pk;
+    memcpy(L.mpk, c->ix.mpk, sizeof L.mpk);
+    L.mw_ok = c->ix.mw_ok;
     uint64_t *tk; uint32_t *ti; uint8_t *fb; uint32_t *fo; uint32_t *ir; uint64_t *gk; uint64_t *pt;
     int rc;
     if ((rc = dev_upload(c, c->ix.tab_keys.data(), c->ix.tab_keys.size(), &tk, c->lib_allocs))) return rc;
@@ -328,6 +330,8 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     if (c->prm.mode != 0) return fail(c, F2Q_ESTATE, "Extract+Count mode takes no feature library (fast2q.py:1701)");
     HIPC(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < n; i++) if (offs[i + 1] < offs[i]) return fail(c, F2Q_EINVAL, "offsets must be non-decreasing");
+    c->plan = make_plan(c->run_h);                   // the library decides below whether the packed paths apply
+    if (c->force_general) { c->plan.fast_fixed = false; c->plan.fast_anchor = false; c->plan.multi = false; }
     int packed_len = c->plan.fast_fixed ? c->run_h.length : 0;
     if (c->plan.fast_anchor) {
         if (c->run_h.has_up && c->run_h.has_down) {          // variable windows: index the most common feature length
@@ -336,7 +340,9 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
             packed_len = (int)(std::max_element(hist.begin(), hist.end()) - hist.begin());
         } else packed_len = c->run_h.length;
     }
-    build_index(c->ix, seqs ? seqs : "", offs, n, c->run_h.miss, packed_len);
+    build_index(c->ix, seqs ? seqs : "", offs, n, c->run_h.miss, packed_len, c->plan.multi ? c->run_h.n_iter : 0);
+    // multi-window runs stay on the packed path only when every reachable feature is a k-part feature
+    if (c->plan.multi && (!c->ix.mw_ok || c->ix.n_irregular)) { c->plan.multi = false; c->plan.fast_fixed = false; }
     int rc = upload_lib(c);
     if (rc) return rc;
     rc = alloc_acc(c, n);
@@ -519,6 +525,29 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
         const bool v2 = !c->force_v1 && c->lib_h.pk.len == (uint32_t)c->run_h.length && c->lib_h.pk.len > 0 &&
                         c->lib_h.n_irregular == 0;
+        if (c->plan.multi) {
+            // several windows per read (--st a,b,...): k-part keys against the k-part features
+            const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
+            const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
+            const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
+            const uint32_t nf_ = c->lib_h.n_features;
+            const size_t need = lds ? (size_t)grid * nf_ : 0;
+            if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
+                if (c->slab_d) (void)hipFree(c->slab_d);
+                if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
+                c->slab_d = nullptr; c->slab_n = 0; c->stat_slab_d = nullptr; c->stat_slab_n = 0;
+                HIPC(c, hipMalloc((void **)&c->slab_d, std::max<size_t>(need, 1) * sizeof(uint32_t)));
+                HIPC(c, hipMalloc((void **)&c->stat_slab_d, (size_t)grid * 8 * sizeof(unsigned long long)));
+                c->slab_n = need; c->stat_slab_n = grid;
+            }
+            acc.slab = c->slab_d; acc.stat_slab = c->stat_slab_d;
+            if (lds) hipLaunchKernelGGL(k_count_multi4<true>, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, pb, acc, c->plan.need);
+            else hipLaunchKernelGGL(k_count_multi4<false>, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, pb, acc, c->plan.need);
+            HIPC(c, hipGetLastError());
+            hipLaunchKernelGGL(k_reduce_slabs, dim3(std::max<uint32_t>(1u, (nf_ + 63) / 64), F2Q_RED_SPLIT), dim3(256), 0, c->stream,
+                               c->slab_d, lds ? grid : 0u, nf_, acc.counts, c->stat_slab_d, grid, acc.stats);
+            launches++;
+        } else {
         const FixedGeom fgeo = fixed_geom(c->run_h);
         // the library in LDS: uniform 14..21-base library, --m <= 1, and tiles that hold every row under the window
         const bool use_lt = v2 && lds && !c->no_lt && c->lib_h.lt.ok && c->lib_h.lt.len == (uint32_t)c->run_h.length &&
@@ -606,6 +635,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
             } else {
                 hipLaunchKernelGGL(k_count_fixed<false>, dim3(grid), dim3(F2Q_TILE), 0, c->stream, c->run_d, c->lib_d, pb, acc);
             }
+        }
         }
         HIPC(c, hipGetLastError());
         launches++;

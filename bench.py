@@ -40,6 +40,8 @@ WORKLOADS = {
     "cfg3_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 3),
     "cfg4_50M_100k_m1": dict(n_reads=50_000_000, n_guides=100000, miss=1, lib_seed=0xF2A5 + 4),
     "cfg4_400M_100k_m1": dict(n_reads=400_000_000, n_guides=100000, miss=1, lib_seed=0xF2A5 + 4),
+    # config 3's reads as a two-window run: --st 0,10 --l 10 against the guides written as first10:last10
+    "cfg3_2win_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 3, windows=2),
     # config 5: up+guide+down cassette at a uniform offset in [0,100]; --us/--ds anchored search
     "cfg5a_50M_10k_anchor_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True),
     "cfg5b_50M_anchor_ec": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True, ec=True),
@@ -98,6 +100,12 @@ def make_job(pkg, w, a, device, n, first_read):
         spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n, cassette=True, up=UP,
                     down=DOWN, max_offset=100)
         blk = c.synth_create(guides=guides, **spec) if w.get("ec") else c.synth_create(**spec)
+    elif w.get("windows") == 2:
+        feats = [g[:10] + ":" + g[10:] for g in guides]
+        c = pkg.Counter(features=feats, miss=w["miss"], phred=a.phred, length=10, start="0,10", device=device)
+        spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n)
+        blk = c.synth_create(guides=guides, **spec)
+        return c, blk, feats, spec
     else:
         c = pkg.Counter(features=guides, miss=w["miss"], phred=a.phred, length=20, start="0", device=device)
         spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n)
@@ -182,6 +190,8 @@ def oracle_kwargs(w, a):
         kw.update(upstream=UP, downstream=DOWN, miss_search_up=a.ms, miss_search_down=a.ms)
         if w.get("ec"):
             kw["mode"] = "EC"
+    elif w.get("windows") == 2:
+        kw.update(length=10, start="0,10")
     else:
         kw.update(length=20, start="0")
     return kw
@@ -303,7 +313,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     name, scaling, w = resolve(a, world)
-    dominant = "k_count_anchor" if w.get("anchored") else "k_count_fixed4"
+    dominant = "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
 
     traffic, traffic_detail = None, {"error": "skipped"}
     if world == 1 and not a.no_pmc:

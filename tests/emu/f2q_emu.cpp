@@ -34,6 +34,7 @@ static void bind_lib(Emu *e)
     L.n_features = e->ix.n_features; L.n_irregular = e->ix.n_irregular;
     L.tab_keys = e->ix.tab_keys.data(); L.tab_idx = e->ix.tab_idx.data();
     L.ptab = e->ix.ptab.data(); L.pk = e->ix.pk;
+    memcpy(L.mpk, e->ix.mpk, sizeof L.mpk); L.mw_ok = e->ix.mw_ok;
     L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
     L.lt = e->ix.lt; L.lt.tags = e->ix.lt_tags.data(); L.lt.slot_of = e->ix.lt_slot_of.data();
     L.lt.feat_of = e->ix.lt_feat_of.data();
@@ -66,6 +67,7 @@ void emu_destroy(void *h) { delete (Emu *)h; }
 void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t n)
 {
     Emu *e = (Emu *)h;
+    e->plan = make_plan(e->run);
     int packed_len = e->plan.fast_fixed ? e->run.length : 0;
     if (e->plan.fast_anchor) {
         if (e->run.has_up && e->run.has_down) {
@@ -74,7 +76,8 @@ void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t 
             packed_len = (int)(std::max_element(hist.begin(), hist.end()) - hist.begin());
         } else packed_len = e->run.length;
     }
-    build_index(e->ix, seqs, offs, n, e->run.miss, packed_len);
+    build_index(e->ix, seqs, offs, n, e->run.miss, packed_len, e->plan.multi ? e->run.n_iter : 0);
+    if (e->plan.multi && (!e->ix.mw_ok || e->ix.n_irregular)) { e->plan.multi = false; e->plan.fast_fixed = false; }
     bind_lib(e);
     e->plan.inband_n = (e->plan.fast_fixed || e->plan.fast_anchor) && e->ix.n_irregular == 0;
     if (e->ix.n_irregular) e->plan.fast_anchor = false;
@@ -225,6 +228,74 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             }
     } else {
     const bool v2 = e->use_v2 && e->lib.pk.len == (uint32_t)e->run.length && e->lib.pk.len > 0 && e->lib.n_irregular == 0;
+    if (e->plan.multi) {
+        // k_count_multi4's per-lane sequence: windows one after another, parts that pass concatenated, k-part tables
+        const int W = e->run.n_iter, L = e->run.length;
+        for (uint32_t t = 0; t < hp.n_tiles; t++)
+            for (uint32_t lane = 0; lane < 64; lane++) {
+                const uint32_t *qp = pb.qual + ((uint64_t)t * pb.wq) * F2Q_TILE + 4 * lane;
+                const uint32_t *bp = pb.bases + ((uint64_t)t * pb.wb) * F2Q_TILE + 4 * lane;
+                uint64_t key[4] = {0, 0, 0, 0}; uint32_t forced[4] = {0, 0, 0, 0}, npart[4] = {0, 0, 0, 0}, lv[4]; int res[4];
+                for (int j = 0; j < 4; j++) {
+                    lv[j] = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
+                    res[j] = lv[j] == F2Q_LEN_SKIP ? R_SKIP : ((int)(lv[j] & 0x7FFFu) < e->plan.need) ? R_SLOW : R_NEAR;
+                }
+                for (int w = 0; w < W; w++) {
+                    const FixedGeom g = fixed_geom_of(e->run, w);
+                    U4 b[F2Q_MAXBROWS], qr[F2Q_MAXQROWS]; uint32_t bad[4] = {0, 0, 0, 0};
+                    for (int r = 0; r < F2Q_MAXBROWS; r++) {
+                        uint32_t row = g.bw0 + (r < g.nb ? r : g.nb - 1);
+                        row = row < pb.wb ? row : pb.wb - 1;
+                        const uint32_t *p = bp + (uint64_t)row * F2Q_TILE; b[r] = U4{p[0], p[1], p[2], p[3]};
+                    }
+                    for (int r = 0; r < F2Q_MAXQROWS; r++) {
+                        uint32_t row = g.qw0 + (r < g.nq ? r : g.nq - 1);
+                        row = row < pb.wq ? row : pb.wq - 1;
+                        const uint32_t *p = qp + (uint64_t)row * F2Q_TILE; qr[r] = U4{p[0], p[1], p[2], p[3]};
+                    }
+                    if (g.add_hi)
+                        for (int r = 0; r < F2Q_MAXQROWS; r++)
+                            if (r < g.nq) fixed4_qrow(g, r, qr[r], bad);
+                    for (int j = 0; j < 4; j++) {
+                        if (res[j] != R_NEAR || bad[j]) continue;
+                        key[j] |= fixed4_key(g, b, j) << (2u * (uint32_t)L * npart[j]);
+                        if (lv[j] & F2Q_LEN_FLAG) forced[j] |= fixed4_flags(g, qr, j) << ((uint32_t)L * npart[j]);
+                        npart[j]++;
+                    }
+                }
+                for (int j = 0; j < 4; j++) {
+                    if (res[j] == R_SKIP) continue;
+                    e->v2_reads++;
+                    if (res[j] == R_SLOW) {
+                        const uint32_t slot = 4 * lane + j; const int r = (int)(lv[j] & 0x7FFFu);
+                        uint8_t sq[F2Q_ANCHOR_MAXLEN], ql[F2Q_ANCHOR_MAXLEN];
+                        const uint32_t *bps = pb.bases + ((uint64_t)t * pb.wb) * F2Q_TILE + slot, *qps = pb.qual + ((uint64_t)t * pb.wq) * F2Q_TILE + slot;
+                        for (int i = 0; i < r; i++) {
+                            sq[i] = (uint8_t)"ACGT"[(bps[(uint64_t)(i >> 4) * F2Q_TILE] >> (2 * (i & 15))) & 3u];
+                            ql[i] = (uint8_t)((qps[(uint64_t)(i >> 2) * F2Q_TILE] >> (8 * (i & 3))) & 0xFFu);
+                            if (ql[i] & 0x80u) { sq[i] = (uint8_t)'N'; ql[i] &= 0x7Fu; }
+                        }
+                        general_read<const uint8_t *>(e->run, e->lib, e->ec, acc, sq, r, ql, r, 0ull, acc.stats);
+                        continue;
+                    }
+                    acc.stats[0]++;
+                    uint32_t idx = 0; int rr;
+                    if (npart[j] == 0) rr = R_QFAIL;
+                    else {
+                        const PackedGroup &pk = e->lib.mpk[npart[j] - 1];
+                        if (forced[j]) rr = (e->run.miss == 0 || __builtin_popcount(forced[j]) > e->run.miss) ? R_NONALIGNED
+                                                                                                             : packed_near_decide(e->run, e->lib, pk, key[j], forced[j], idx);
+                        else {
+                            const int ex = pk.len ? packed_exact(e->lib, pk, key[j]) : -1;
+                            if (ex >= 0) { rr = R_PERFECT; idx = (uint32_t)ex; }
+                            else rr = e->run.miss > 0 ? packed_near_decide(e->run, e->lib, pk, key[j], 0u, idx) : R_NONALIGNED;
+                        }
+                    }
+                    if (rr == R_PERFECT || rr == R_IMPERFECT) acc.counts[idx]++;
+                    acc.stats[rr]++;
+                }
+            }
+    } else
     if (v2) {
         // the v2 kernel's per-lane sequence: 4 reads per lane from 16-byte row loads, packed tables
         const FixedGeom g = fixed_geom(e->run);

@@ -465,6 +465,64 @@ def test_lds_table_kernel_vs_oracle(P, monkeypatch, miss, glen, n_guides, start,
     assert list(stats2) == list(stats) and list(counts2) == list(counts)
 
 
+@pytest.mark.parametrize("miss", [0, 1, 2])
+@pytest.mark.parametrize("starts,length,rl", [("0,10", 10, 40), ("3,20,9", 6, 33), ("12,0", 15, 30), ("0,7,14,21", 6, 31), ("5,5", 8, 20)])
+def test_multi_window_packed_kernel_vs_oracle(P, monkeypatch, miss, starts, length, rl):
+    """k_count_multi4 (--st a,b,... on packed tiles, k-part feature tables) against the oracle and against the byte-exact
+    general kernel; runs whose joint key does not fit the packed slot must stay on the general path"""
+    from test_lane_logic_cpu import multi_window_case
+    lib, fq, W = multi_window_case(starts, length, rl, miss, n_reads=40000)
+    kw = dict(miss=miss, length=length, start=starts)
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    with P.Counter(features=lib, **kw) as c:
+        _, t = c.count_block(fq, want_timing=True)
+        counts, stats = c.read_counts()
+    assert list(stats) == o.stats() and list(counts) == o.counts()
+    packed = 2 * W * length + len(lib).bit_length() <= 64
+    assert (t["general_reads"] == 0) if packed else (t["fast_reads"] == 0)
+    monkeypatch.setenv("F2Q_FORCE_GENERAL", "1")
+    with P.Counter(features=lib, **kw) as c:
+        _, t2 = c.count_block(fq, want_timing=True)
+        counts2, stats2 = c.read_counts()
+    monkeypatch.delenv("F2Q_FORCE_GENERAL")
+    assert t2["fast_reads"] == 0 and list(stats2) == list(stats) and list(counts2) == list(counts)
+
+
+def test_two_window_full_size(P, monkeypatch):
+    """50M reads, two 10-base windows (--st 0,10 --l 10) against 10k two-part features: the packed multi-window kernel
+    against the single-window run of the 20-base form of the same library on the same reads (same counts: see below),
+    the byte-exact general kernel on a 5M slice, and the identities"""
+    guides = P.binding.synth_library(0xF2A5 + 3, 10000, 20)
+    lib2 = [g[:10] + ":" + g[10:] for g in guides]
+    spec = dict(seed=0xBEEF, n_reads=50_000_000, read_len=150)
+    kw = dict(miss=1, phred=30, length=10, start="0,10")
+    with P.Counter(features=lib2, **kw) as c:
+        blk = c.synth_create(guides=guides, **spec)
+        t2 = c.count_resident(blk)
+        c2, s2 = c.read_counts()
+        blk.free()
+    assert t2["general_reads"] == 0 and s2[0] == 50_000_000 and s2[0] == sum(s2[1:]) and c2.sum() == s2[1] + s2[2]
+    c1, s1, _, _ = _full(P, monkeypatch, {}, guides, spec, miss=1, phred=30, length=20, start="0")
+    # both parts pass <=> the 20-base window passes, and then the verdicts are the same (the ':' sits between the halves);
+    # a read with one failed part yields a one-part key, and the library has no one-part feature
+    assert c1 == list(c2) and s1[1:3] == list(s2[1:3]) and s1[3] + s1[4] == s2[3] + s2[4] and s2[4] < s1[4]
+    sl = dict(spec, n_reads=5_000_000)
+    res = []
+    for env in ({}, {"F2Q_FORCE_GENERAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with P.Counter(features=lib2, **kw) as c:
+            blk = c.synth_create(guides=guides, **sl)
+            t = c.count_resident(blk)
+            cc, ss = c.read_counts()
+            res.append((list(cc), list(ss), t["general_reads"]))
+            blk.free()
+        for k in env:
+            monkeypatch.delenv(k)
+    assert res[0][:2] == res[1][:2] and res[0][2] == 0 and res[1][2] == 5_000_000
+
+
 def test_lds_histogram_overflow_protocol(P, monkeypatch):
     """two guides take 40M reads: every workgroup's u16 counters pass 0x8000 several times and hand the surplus to the
     global vector; the result must equal the pigeonhole kernel's (u32 histogram) bit for bit"""

@@ -107,6 +107,64 @@ def test_lds_tables_vs_oracle(miss, glen, n_guides, start):
     assert e2.read()[:2] == (counts, stats) and e2.lt_reads() == 0
 
 
+def multi_window_case(starts, length, rl, miss, n_reads=5000):
+    """(library, FASTQ bytes, windows) of a seeded multi-window run: features of every part count, parts of a feature
+    planted at the windows, substitutions / N, low-quality bases, reads that end inside a window"""
+    import random
+    rng = random.Random(len(starts) * 100 + length + miss)
+    st = [int(x) for x in starts.split(",")]
+    W = len(st)
+    base = synth.make_library(120, length, 50 + length)
+    lib = []
+    for _ in range(300):
+        k = rng.randint(1, W)
+        lib.append(":".join(rng.choice(base) for _ in range(k)))
+    lib = list(dict.fromkeys(lib))
+    lines = []
+    for i in range(n_reads):
+        n = rl if rng.random() > 0.06 else rng.randint(0, rl - 1)
+        seq = [rng.choice("ACGT") for _ in range(rl)]
+        feat = rng.choice(lib).split(":")
+        for w, s0 in enumerate(st):                                   # plant parts of a feature (or other parts) at the windows
+            part = feat[w % len(feat)] if rng.random() < 0.8 else rng.choice(base)
+            seq[s0:s0 + length] = list(part)[: max(0, rl - s0)]
+        for _ in range(rng.choice([0, 0, 0, 1, 1, 2])):
+            p = rng.randrange(rl); seq[p] = rng.choice("ACGTN")
+        q = ["I"] * rl
+        for _ in range(rng.choice([0, 0, 1, 2])):
+            q[rng.randrange(rl)] = rng.choice("#5>=")
+        lines.append(f"@r{i}\n{''.join(seq)[:n]}\n+\n{''.join(q)[:n]}\n")
+    return lib, "".join(lines).encode(), W
+
+
+@pytest.mark.parametrize("miss", [0, 1, 2])
+@pytest.mark.parametrize("starts,length,rl", [("0,10", 10, 40), ("3,20,9", 6, 33), ("12,0", 15, 30), ("0,7,14,21", 6, 31), ("5,5", 8, 20), ("0,9,18", 9, 30)])
+def test_multi_window_packed_logic_vs_oracle(miss, starts, length, rl):
+    """k_count_multi4's per-lane logic (--st a,b,...: ':'-joined parts, failed parts omitted, k-part features) against
+    the oracle: libraries holding features of every part count, low-quality parts, N symbols, reads that end inside a
+    window (byte-exact routine on a copy rebuilt from the tile)"""
+    lib, fq, W = multi_window_case(starts, length, rl, miss)
+    kw = dict(miss=miss, length=length, start=starts)
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    e = Emu(features=lib, **kw)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats() and counts == o.counts()
+    # the packed slot holds key and feature index in one u64: longer joint keys keep the byte-exact general path
+    packed = 2 * W * length + len(lib).bit_length() <= 64
+    assert (gen == 0 and e.v2_reads() == 5000) if packed else (fast == 0 and gen == 5000)
+    assert packed or (starts, length) == ("12,0", 15)
+    # a plain feature as long as a joined key makes the run fall back to the byte-exact general path
+    lib2 = lib + ["A" * (2 * length + 1)]
+    o2 = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib2)], **kw)
+    o2.count_fastq(fq)
+    e2 = Emu(features=lib2, **kw)
+    e2.count_block(fq)
+    c2, s2, fast2, gen2 = e2.read()
+    assert s2 == o2.stats() and c2 == o2.counts() and fast2 == 0 and gen2 == 5000
+
+
 def test_lds_tables_applicability():
     """built only for uniform ACGT libraries of 14..21-base features searched with --m <= 1 that fit the tables"""
     g20 = synth.make_library(500, 20, 1)
