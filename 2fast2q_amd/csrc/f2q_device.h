@@ -140,7 +140,7 @@ struct EcDev {
     unsigned long long *k64_slots;
     unsigned long long *k64_count;
     unsigned long long *k64_first;
-    uint32_t k64_mask, k64_pad;
+    uint32_t k64_mask, k64_room;       // slots - 1; keys the table may hold before it grows (3/4 of the slots)
 };
 #define F2Q_EC64_MAXLEN 29
 

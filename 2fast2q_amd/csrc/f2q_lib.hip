@@ -394,8 +394,10 @@ extern "C" int f2q_counts_device_ptr(f2q_ctx *c, void **dptr, uint64_t *n_int64)
 static int ec_alloc(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t max_entries, uint64_t arena_words)
 {
     memset(&e, 0, sizeof e);
+    // load factor <= 0.75 even if every read of a launch brings a new key (usually a small fraction of that): smaller
+    // tables are cheaper to clear and stay in the Infinity Cache longer
     uint64_t slots = 1024;
-    while (slots < 2 * max_entries) slots <<= 1;
+    while (3 * slots < 4 * max_entries) slots <<= 1;
     if (slots > (1ull << 32)) return fail(c, F2Q_ENOMEM, "Extract+Count table would exceed 2^32 slots");
     int rc;
     if ((rc = dev_alloc(c, slots, &e.slots, owner, 0))) return rc;
@@ -410,6 +412,7 @@ static int ec_alloc(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t m
     if ((rc = dev_alloc(c, slots, &e.k64_first, owner, 0xFF))) return rc;
     e.k64_mask = (uint32_t)(slots - 1);
     e.mask = (uint32_t)(slots - 1); e.max_entries = (uint32_t)std::min<uint64_t>(max_entries, 0xFFFFFFFEull);
+    e.k64_room = (uint32_t)std::min<uint64_t>(3 * slots / 4, 0xFFFFFFFEull);   // keys the single-word table takes before it must grow
     e.arena_words = arena_words;
     return F2Q_OK;
 }
@@ -423,11 +426,13 @@ static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
         HIPC(c, hipStreamSynchronize(c->stream));
         if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error)");
     }
-    // both tables are sized for "every read brings a new key": slots = 2 * max_entries
+    // both tables have room for "every read of the launch brings a new key" (at most 3/4 of the slots used)
     const uint64_t need_e = std::max(ctr[0], ctr[3]) + reads + 16, need_w = ctr[1] + (key_bytes + 3) / 4 + reads + 16;
-    if (c->ec.slots && need_e <= c->ec.max_entries && need_w <= c->ec.arena_words) return F2Q_OK;
+    // the byte-string table is limited by its entry arrays, the single-word table by its load factor
+    const uint64_t need_b = ctr[0] + reads + 16, need_r = ctr[3] + reads + 16;
+    if (c->ec.slots && need_b <= c->ec.max_entries && need_r <= c->ec.k64_room && need_w <= c->ec.arena_words) return F2Q_OK;
     // growth doubles the room of the keys already there (amortised rehash), not the head room of one launch
-    uint64_t ne = std::max<uint64_t>(need_e + std::max<uint64_t>(std::max(ctr[0], ctr[3]), reads / 2), 1u << 16);
+    uint64_t ne = std::max<uint64_t>(need_e + std::max<uint64_t>(std::max(ctr[0], ctr[3]), reads / 4), 1u << 16);
     uint64_t nw = std::max<uint64_t>(need_w + std::max<uint64_t>(ctr[1], key_bytes / 16), 1u << 18);
     const double rs0 = now_ms();
     if (c->ec.slots && (ctr[0] || ctr[3])) {
