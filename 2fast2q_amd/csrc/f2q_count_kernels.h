@@ -971,6 +971,158 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     }
 }
 
+// ---- anchored runs with the library in LDS ---------------------------------------------------------------------
+// k_count_anchor's extraction stage (bit-plane tiles, bit-parallel anchor search, fail vectors) in front of
+// k_count_fixed4_lds's matching stage: Counter mode, uniform library of 14..21-base features, --m <= 1.  Every window
+// of another length than the features can equal or approach none of them (fast2q.py:683), so the only lookups are
+// the four LDS bucket reads of lt_decide: no table traffic to L2, no ring, no drain, and -- nothing else in the loop
+// touching memory -- the rows of the group's next tile really do travel while the current tile is searched.
+// One workgroup per CU (the LDS tables take all of it); each group of 256 threads walks tiles like a k_count_anchor
+// workgroup does.
+#ifndef F2Q_ALT_THREADS
+#define F2Q_ALT_THREADS 768
+#endif
+#define F2Q_ALT_GROUPS (F2Q_ALT_THREADS / F2Q_TILE)
+
+template <int NW, int KB, bool SAMEQ, bool NEAR>
+__global__ __launch_bounds__(F2Q_ALT_THREADS) void k_count_anchor_lt(const RunDev *__restrict__ runp,
+                                                                    const LibDev *__restrict__ libp, PackedBlock pb,
+                                                                    Accum acc)
+{
+    constexpr int NQW = 8 * NW;
+    extern __shared__ uint32_t lt_smem[];
+    constexpr uint32_t NT = NEAR ? 2u : 1u;
+    uint32_t *tg = lt_smem;                                     // [NT][F2Q_LT_SLOTS] tags
+    uint32_t *cnt = lt_smem + NT * F2Q_LT_SLOTS;                // [F2Q_LT_BUCKETS] two u16 counters per word
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const LtDesc lt = lib.lt;
+    const uint32_t nf = lib.n_features;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, slot_in_tile = tid & (F2Q_TILE - 1u), group = tid / F2Q_TILE;
+    {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(lt.tags);
+        v4 *dst = reinterpret_cast<v4 *>(tg);
+        for (uint32_t i = tid; i < NT * F2Q_LT_SLOTS / 4u; i += F2Q_ALT_THREADS) dst[i] = src[i];
+        for (uint32_t i = tid; i < F2Q_LT_BUCKETS; i += F2Q_ALT_THREADS) cnt[i] = 0;
+    }
+    __syncthreads();
+    const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
+    const int flen = (int)lt.len;
+    uint32_t w_reads = 0, w_perfect = 0, w_imperfect = 0, w_qfail = 0;      // this wave's counters (scalar registers)
+    unsigned long long st_slow[5] = {0, 0, 0, 0, 0};                         // reads that took the byte-exact routine
+
+    struct Planes { uint32_t lo[NW], hi[NW], q[NQW], len; };
+    const auto b_base = gp(pb.bases) + slot_in_tile, q_base = gp(pb.qual) + slot_in_tile;
+    const auto l_base = gp(pb.len) + slot_in_tile;
+    const uint64_t b_stride = (uint64_t)pb.wb * F2Q_TILE, q_stride = (uint64_t)pb.wq * F2Q_TILE;
+    // unconditional, fixed number of loads per tile (the host guarantees the length plane): exact wait counts
+    auto request_tile = [&](Planes &p, uint32_t t) {
+        const auto bp = b_base + (uint64_t)t * b_stride, qp = q_base + (uint64_t)t * q_stride;
+        p.len = l_base[(uint64_t)t * F2Q_TILE];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            p.lo[w] = __builtin_nontemporal_load(bp + (uint64_t)w * F2Q_TILE);
+            p.hi[w] = __builtin_nontemporal_load(bp + (uint64_t)(NW + w) * F2Q_TILE);
+        }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) p.q[i] = __builtin_nontemporal_load(qp + (uint64_t)i * F2Q_TILE);
+    };
+    auto decide_tile = [&](const Planes &p, uint32_t tile) {
+        const uint32_t l = p.len;
+        uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW], FLG[NW];
+        const bool live = l != F2Q_LEN_SKIP;
+        const bool flagged = live && (l & F2Q_LEN_FLAG);
+        if (__ballot(flagged) == 0ull) {              // the usual tile: no flag bits to strip, no flag planes to build
+#pragma unroll
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q8[i] = p.q[8 * cw + i];
+                FW[cw] = fail_word8<false>(q8, ah_w);
+                if (!SAMEQ) { FU[cw] = fail_word8<false>(q8, ah_u); FD[cw] = fail_word8<false>(q8, ah_d); }
+                FLG[cw] = 0u;
+            }
+        } else {
+#pragma unroll
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q8[i] = p.q[8 * cw + i];
+                FW[cw] = fail_word8(q8, ah_w);
+                if (!SAMEQ) { FU[cw] = fail_word8(q8, ah_u); FD[cw] = fail_word8(q8, ah_d); }
+                FLG[cw] = flagged ? flag_word8(q8) : 0u;
+            }
+        }
+        const int r = (int)(l & 0x7FFFu);
+        AnchorWin aw;
+        if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FW, FW, FW);
+        else aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FU, FD, FW);
+        const int L = aw.end - aw.start;
+        const bool qf = live && aw.ok == 0;
+        const bool slow = live && aw.ok == 2;
+        // a window of another length than the features passed its Phred test but can equal or approach none of them
+        const bool cand = live && aw.ok == 1 && L == flen;
+        w_reads += (uint32_t)__popcll(__ballot(live && !slow));
+        w_qfail += (uint32_t)__popcll(__ballot(qf));
+        if (slow) {
+            // negative-index slices (down-only anchor near the read start, negative --l): byte-exact routine
+            const EcDev ec2{}; const Accum acc2 = acc; const PackedBlock pb2 = pb;
+            anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, slot_in_tile, r, 0ull, st_slow);
+        }
+        const int ws = cand ? aw.start : 0;
+        const uint32_t forced = (cand && flagged) ? plane_extract<NW>(FLG, ws, flen) : 0u;
+        const LtProbe q = lt_probe(lt, plane_key<NW>(p.lo, p.hi, ws, flen));
+        U2 e[4];
+#pragma unroll
+        for (int k = 0; k < (NEAR ? 4 : 2); k++) e[k] = lds_u2(tg + (uint32_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q.b[k]);
+        if (!NEAR) { e[2] = U2{F2Q_LT_EMPTY, F2Q_LT_EMPTY}; e[3] = e[2]; }
+        const LtVerdict v = lt_decide<NEAR>(lt, q, e, forced, [&](uint32_t bk) { return lds_u2(tg + 2u * bk); });
+        const LtPred cm = LT_P(cand), perfect = v.perfect & cm, imperfect = v.imperfect & cm;
+        if (LT_TRUE(perfect | imperfect)) lt_count(cnt, v.slot, acc, lt);
+        w_perfect += (uint32_t)__popcll(perfect);
+        w_imperfect += (uint32_t)__popcll(imperfect);
+    };
+
+    const uint32_t stride = gridDim.x * F2Q_ALT_GROUPS, last = pb.n_tiles - 1u;
+    uint32_t tile = blockIdx.x * F2Q_ALT_GROUPS + group;
+    {
+        Planes pa, pb2;
+        if (tile < pb.n_tiles) {
+            request_tile(pa, tile);
+            for (;;) {
+                __builtin_amdgcn_sched_barrier(0);
+                request_tile(pb2, min(tile + stride, last));
+                __builtin_amdgcn_sched_barrier(0);
+                decide_tile(pa, tile);
+                tile += stride;
+                if (tile >= pb.n_tiles) break;
+                __builtin_amdgcn_sched_barrier(0);
+                request_tile(pa, min(tile + stride, last));
+                __builtin_amdgcn_sched_barrier(0);
+                decide_tile(pb2, tile);
+                tile += stride;
+                if (tile >= pb.n_tiles) break;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        auto row = gpw(acc.slab) + (uint64_t)blockIdx.x * nf;
+        for (uint32_t i = tid; i < nf; i += F2Q_ALT_THREADS) {
+            const uint32_t s = gp(lt.slot_of)[i];
+            row[i] = (cnt[s >> 1] >> ((s & 1u) << 4)) & 0xFFFFu;
+        }
+    }
+    __syncthreads();
+    const bool l0 = lane == 0;
+    unsigned long long stv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) stv[k] = st_slow[k];
+    if (l0) { stv[0] += w_reads; stv[1] += w_perfect; stv[2] += w_imperfect; stv[3] += w_reads - w_perfect - w_imperfect - w_qfail; stv[4] += w_qfail; }
+    flush_stats(acc, stv, reinterpret_cast<unsigned long long *>(lt_smem), acc.stat_slab + (uint64_t)blockIdx.x * 8u);
+}
+
 // Large libraries (no per-workgroup LDS histogram of the whole library): the counting kernel leaves the feature index
 // of every read in hit_buf; here workgroup (range, part) histograms the indices of its part that fall into its range
 // of F2Q_HIST_MAX features in LDS and writes that stretch of slab row `part`.  hit_buf is read n_ranges times, from

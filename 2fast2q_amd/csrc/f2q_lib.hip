@@ -493,6 +493,42 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         }
         const int nw = (int)pb.planar_nw, kb = c->plan.kb;
         const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
+        // the library in LDS (Counter mode, uniform 14..21-base library, --m <= 1, default --qsu/--qsd)
+        if (!ecm && lds && sameq && !c->no_lt && c->lib_h.lt.ok && c->run_h.miss <= 1 && pb.len != nullptr) {
+            const uint32_t groups = (pb.n_tiles + F2Q_ALT_GROUPS - 1) / F2Q_ALT_GROUPS;
+            const uint32_t lgrid = std::min<uint32_t>(groups, (uint32_t)c->n_cu);
+            const bool near = c->run_h.miss > 0;
+            const size_t lshmem = ((near ? 2u : 1u) * (size_t)F2Q_LT_SLOTS + F2Q_LT_BUCKETS) * 4;
+            const uint32_t nf_ = c->lib_h.n_features;
+            const size_t need = (size_t)lgrid * nf_;
+            if (need > c->slab_n || (size_t)lgrid > c->stat_slab_n) {
+                if (c->slab_d) (void)hipFree(c->slab_d);
+                if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
+                c->slab_d = nullptr; c->slab_n = 0; c->stat_slab_d = nullptr; c->stat_slab_n = 0;
+                HIPC(c, hipMalloc((void **)&c->slab_d, std::max<size_t>(need, 1) * sizeof(uint32_t)));
+                HIPC(c, hipMalloc((void **)&c->stat_slab_d, (size_t)lgrid * 8 * sizeof(unsigned long long)));
+                c->slab_n = need; c->stat_slab_n = lgrid;
+            }
+            acc.slab = c->slab_d; acc.stat_slab = c->stat_slab_d;
+#define F2Q_LAUNCH_ALT(NW_, KB_)                                                                                       \
+            do {                                                                                                       \
+                auto kern = near ? k_count_anchor_lt<NW_, KB_, true, true> : k_count_anchor_lt<NW_, KB_, true, false>;  \
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lshmem);\
+                hipLaunchKernelGGL(kern, dim3(lgrid), dim3(F2Q_ALT_THREADS), lshmem, c->stream, c->run_d, c->lib_d, pb, acc); \
+            } while (0)
+            if (nw == 3 && kb == 0) F2Q_LAUNCH_ALT(3, 0);
+            else if (nw == 3 && kb == 1) F2Q_LAUNCH_ALT(3, 1);
+            else if (nw == 3) F2Q_LAUNCH_ALT(3, 3);
+            else if (kb == 0) F2Q_LAUNCH_ALT(5, 0);
+            else if (kb == 1) F2Q_LAUNCH_ALT(5, 1);
+            else F2Q_LAUNCH_ALT(5, 3);
+#undef F2Q_LAUNCH_ALT
+            HIPC(c, hipGetLastError());
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((nf_ + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
+                               c->slab_d, lgrid, nf_, acc.counts, c->stat_slab_d, lgrid, acc.stats);
+            HIPC(c, hipGetLastError());
+            launches += 2;
+        } else {
 #define F2Q_LAUNCH_AN2(NW_, KB_, SQ_)                                                                                \
         do {                                                                                                         \
             if (ecm) hipLaunchKernelGGL((k_count_anchor<NW_, KB_, true, false, SQ_>), dim3(grid), dim3(F2Q_AN_THREADS),   \
@@ -519,6 +555,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
                                c->slab_d, grid, c->lib_h.n_features, acc.counts, c->stat_slab_d, grid, acc.stats);
             HIPC(c, hipGetLastError());
             launches++;
+        }
         }
     } else if (pb.n_tiles && c->prm.mode == 1) {
         const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
