@@ -16,7 +16,7 @@ STAT_NAMES = ("reads", "perfect_counter", "imperfect_counter", "non_aligned_coun
 
 EXPORTS = (
     "f2q_version", "f2q_build_id", "f2q_create", "f2q_destroy", "f2q_last_error", "f2q_set_features", "f2q_count_block",
-    "f2q_count_file", "f2q_count_file_shard", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
+    "f2q_count_file", "f2q_count_file_shard", "f2q_file_pieces", "f2q_census_pieces", "f2q_count_pieces", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
     "f2q_block_free", "f2q_synth_fastq", "f2q_synth_library", "f2q_reset_counts", "f2q_read_counts",
     "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base", "f2q_synth_guides",
 )
@@ -135,6 +135,9 @@ def load(path=None):
     L.f2q_count_block.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Timing)]
     L.f2q_count_file.argtypes = [vp, C.c_char_p, C.POINTER(Timing)]
     L.f2q_count_file_shard.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(Timing)]
+    L.f2q_file_pieces.argtypes = [C.c_char_p, C.c_uint64, u64p, C.POINTER(C.c_int)]
+    L.f2q_census_pieces.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_uint64]
+    L.f2q_count_pieces.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_uint64, C.POINTER(Timing)]
     L.f2q_synth_create.argtypes = [vp, C.POINTER(Synth), C.POINTER(vp)]
     L.f2q_block_from_fastq.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     L.f2q_count_resident.argtypes = [vp, vp, C.POINTER(Timing)]
@@ -280,6 +283,31 @@ class Counter:
             return t.as_dict(), True
         self._check(rc)
         return t.as_dict(), False
+
+    # -- a plain file shared out by pieces: nobody reads foreign bytes (include/f2q.h, f2q_file_pieces ...) --
+    def file_pieces(self, path, piece_bytes):
+        """(number of pieces, shardable)"""
+        n, ok = C.c_uint64(), C.c_int()
+        rc = self._L.f2q_file_pieces(os.fsencode(path), piece_bytes, C.byref(n), C.byref(ok))
+        if rc:
+            raise F2QError(rc, (self._L.f2q_last_error(None) or b"").decode())
+        return n.value, bool(ok.value)
+
+    def census_pieces(self, path, rank, world, piece_bytes, n_pieces):
+        """uint64[2 * n_pieces]: newline count and ends-with-newline flag of this rank's pieces (zeros elsewhere)"""
+        census = np.zeros(2 * n_pieces, dtype=np.uint64)
+        rc = self._L.f2q_census_pieces(os.fsencode(path), rank, world, piece_bytes, census.ctypes.data_as(C.POINTER(C.c_uint64)), n_pieces)
+        if rc:
+            raise F2QError(rc, (self._L.f2q_last_error(None) or b"").decode())
+        return census
+
+    def count_pieces(self, path, rank, world, piece_bytes, census):
+        """counts the records that start in this rank's pieces; census = the ranks' census vectors summed"""
+        census = np.ascontiguousarray(census, dtype=np.uint64)
+        t = Timing()
+        self._check(self._L.f2q_count_pieces(self._h, os.fsencode(path), rank, world, piece_bytes,
+                                             census.ctypes.data_as(C.POINTER(C.c_uint64)), len(census) // 2, C.byref(t)))
+        return t.as_dict()
 
     def block_from_fastq(self, data):
         data = bytes(data)

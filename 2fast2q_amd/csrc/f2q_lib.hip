@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <chrono>
 #include <condition_variable>
@@ -849,7 +850,7 @@ static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_bloc
 struct DevText { void *buf = nullptr; size_t cap = 0; uint8_t *text = nullptr; uint8_t last_byte = 0; };
 
 static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_block **out,
-                                  const DevText *pre = nullptr)
+                                  const DevText *pre = nullptr, uint64_t max_records = ~0ull)
 {
     *out = nullptr; *consumed = 0;
     f2q_block *b = new f2q_block();
@@ -884,7 +885,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     ING(hipStreamSynchronize(c->stream));
     const bool open_tail = nbytes > 0 && (pre ? pre->last_byte : fastq[nbytes - 1]) != '\n';
     const uint64_t n_lines = (uint64_t)n_newlines + (open_tail ? 1 : 0);
-    const uint32_t n_rec = (uint32_t)(n_lines / 4);
+    const uint32_t n_rec = (uint32_t)std::min<uint64_t>(n_lines / 4, max_records);   // (a piece of a sharded file owns only the records that start in it)
     uint32_t *d_ls;
     if ((rc = dev_alloc(c, (size_t)n_newlines + 2, &d_ls, tmp))) return bail(rc);
     hipLaunchKernelGGL(k_line_starts, dim3(n_chunks), dim3(256), 0, c->stream, d_text, (uint64_t)nbytes, d_cp, d_ls);
@@ -966,12 +967,13 @@ extern "C" int f2q_block_from_fastq(f2q_ctx *c, const uint8_t *fastq, size_t nby
 }
 
 // one window of text (at most 1 GiB: the device packer indexes it with 32 bits): frame, pack, count, free
-static int count_window(f2q_ctx *c, const uint8_t *fastq, size_t take, const DevText *pre, size_t *used_out, f2q_timing *one)
+static int count_window(f2q_ctx *c, const uint8_t *fastq, size_t take, const DevText *pre, size_t *used_out, f2q_timing *one,
+                        uint64_t max_records = ~0ull)
 {
     f2q_block *b = nullptr; size_t used = 0;
     int rc;
     const double t0 = now_ms();
-    if (!c->host_pack || pre) rc = block_from_text_device(c, fastq, take, &used, &b, pre);
+    if (!c->host_pack || pre || max_records != ~0ull) rc = block_from_text_device(c, fastq, take, &used, &b, pre, max_records);
     else {
         std::vector<Rec> recs;
         used = frame_fastq(fastq, take, recs);
@@ -1264,6 +1266,217 @@ extern "C" int f2q_count_file(f2q_ctx *c, const char *path, f2q_timing *t) { ret
 extern "C" int f2q_count_file_shard(f2q_ctx *c, const char *path, uint32_t rank, uint32_t world, f2q_timing *t)
 {
     return count_file_impl(c, path, rank, world, t);
+}
+
+// ---- one plain file counted by several processes without anybody reading foreign bytes ------------------------------
+// The 4-line framing is global (fast2q.py:324-328: a record is lines 4i..4i+3 of the FILE), so a rank can only frame its
+// share once it knows how many lines precede it.  The file is cut into pieces of piece_bytes, piece k belongs to rank
+// k % world, and the work is split in two steps around ONE small all-reduce that the caller does (it owns the
+// communicator): (1) every rank counts the newlines of ITS pieces (f2q_census_pieces), (2) with the summed census every
+// rank knows the line index at which each of its pieces starts and counts the records whose first line STARTS in
+// its pieces, reading on past the piece's end only to finish its last record (f2q_count_pieces).
+struct PieceSpan { uint64_t base, size; };
+static inline PieceSpan piece_span(uint64_t file_size, uint64_t piece_bytes, uint64_t k)
+{
+    const uint64_t base = k * piece_bytes;
+    return PieceSpan{base, base < file_size ? std::min<uint64_t>(piece_bytes, file_size - base) : 0};
+}
+
+extern "C" int f2q_file_pieces(const char *path, uint64_t piece_bytes, uint64_t *n_pieces, int *shardable)
+{
+    if (!path || !n_pieces || !shardable || piece_bytes < 4096) return F2Q_EINVAL;
+    *n_pieces = 0; *shardable = 0;
+    TextSource src; std::string err;
+    if (src.open(path, err) != 0) { g_create_err = err; return F2Q_EIO; }
+    if (src.kind == TextSource::PLAIN && src.regular) {
+        *shardable = 1;
+        *n_pieces = (src.file_size + piece_bytes - 1) / piece_bytes;
+    }
+    return F2Q_OK;
+}
+
+// census[2k] = newlines in piece k, census[2k+1] = 1 if its last byte is a newline; only this rank's pieces are written
+extern "C" int f2q_census_pieces(const char *path, uint32_t rank, uint32_t world, uint64_t piece_bytes, uint64_t *census, uint64_t n_pieces)
+{
+    if (!path || !census || world == 0 || rank >= world || piece_bytes < 4096) return F2Q_EINVAL;
+    TextSource src; std::string err;
+    if (src.open(path, err) != 0) { g_create_err = err; return F2Q_EIO; }
+    if (!(src.kind == TextSource::PLAIN && src.regular)) { g_create_err = "not a plain regular file"; return F2Q_EUNSUPPORTED; }
+    const int T = src.n_threads;
+    const size_t SL = (size_t)4 << 20;                                  // bytes per pread
+    std::vector<std::vector<uint8_t>> bufs((size_t)T);
+    for (uint64_t k = rank; k < n_pieces; k += world) {
+        const PieceSpan sp = piece_span(src.file_size, piece_bytes, k);
+        if (sp.size == 0) { census[2 * k] = 0; census[2 * k + 1] = 0; continue; }
+        const uint64_t n_sl = (sp.size + SL - 1) / SL;
+        std::vector<uint64_t> cnt((size_t)T, 0);
+        std::atomic<uint64_t> next{0};
+        std::atomic<bool> bad{false};
+        auto work = [&](int t) {
+            std::vector<uint8_t> &b = bufs[(size_t)t];
+            if (b.size() < SL) b.resize(SL);
+            for (;;) {
+                const uint64_t i = next.fetch_add(1);
+                if (i >= n_sl) return;
+                const uint64_t off = sp.base + i * SL, len = std::min<uint64_t>(SL, sp.base + sp.size - off);
+                uint64_t o = 0;
+                while (o < len) { ssize_t r = pread(src.fd, b.data() + o, len - o, (off_t)(off + o)); if (r <= 0) { bad = true; return; } o += (uint64_t)r; }
+                uint64_t n = 0;
+                for (uint64_t j = 0; j < len; j++) n += (b[j] == 0x0a);
+                cnt[(size_t)t] += n;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        if (bad) { g_create_err = "short read"; return F2Q_EIO; }
+        uint64_t nl = 0; for (uint64_t v : cnt) nl += v;
+        uint8_t lastb = 0;
+        if (pread(src.fd, &lastb, 1, (off_t)(sp.base + sp.size - 1)) != 1) { g_create_err = "short read"; return F2Q_EIO; }
+        census[2 * k] = nl; census[2 * k + 1] = lastb == 0x0a ? 1 : 0;
+    }
+    return F2Q_OK;
+}
+
+extern "C" int f2q_count_pieces(f2q_ctx *c, const char *path, uint32_t rank, uint32_t world, uint64_t piece_bytes,
+                                const uint64_t *census, uint64_t n_pieces, f2q_timing *t)
+{
+    if (!c || !path || !census || world == 0 || rank >= world || piece_bytes < 4096) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    TextSource src;
+    { std::string err; if (src.open(path, err) != 0) return fail(c, F2Q_EIO, err); }
+    if (!(src.kind == TextSource::PLAIN && src.regular)) return fail(c, F2Q_EUNSUPPORTED, "f2q_count_pieces takes a plain regular file");
+    if (n_pieces != (src.file_size + piece_bytes - 1) / piece_bytes) return fail(c, F2Q_EINVAL, "census does not fit the file");
+    // what this rank owns: for every piece the text offset of its first record start, the number of records, the read index
+    struct Job { uint64_t k, skip_lines, n_records, first_read; bool at_line_start; };
+    std::vector<Job> jobs;
+    {
+        uint64_t lines_before = 0;                         // newlines before the piece = index of the line its first byte is in
+        for (uint64_t k = 0; k < n_pieces; k++) {
+            const bool at_start = k == 0 || census[2 * (k - 1) + 1] != 0;
+            const uint64_t nl = census[2 * k], last_nl = census[2 * k + 1];
+            const uint64_t starts = (at_start ? 1 : 0) + nl - (last_nl ? 1 : 0);          // lines that START in the piece
+            const uint64_t i0 = at_start ? lines_before : lines_before + 1;              // index of the first of them
+            const uint64_t r0 = (i0 + 3) / 4 * 4;                                        // first record start at or after it
+            if (k % world == rank && starts > r0 - i0) {
+                const uint64_t left = starts - (r0 - i0);
+                jobs.push_back(Job{k, r0 - i0, (left + 3) / 4, r0 / 4, at_start});
+            }
+            lines_before += nl;
+        }
+    }
+    const size_t HEAD = 64, MARGIN = (size_t)1 << 20;       // a record that starts in the piece ends within the margin behind it
+    constexpr int NSLOT = 3;
+    PinBuf buf[NSLOT];
+    auto drop = [&]() { for (auto &b : buf) g_pinned.release(b); };
+    const size_t cap = HEAD + (size_t)std::min<uint64_t>(piece_bytes, std::max<uint64_t>(src.file_size, 4096)) + MARGIN;
+    for (auto &b : buf) if (!g_pinned.acquire(cap, b)) { drop(); return fail(c, F2Q_ENOMEM, "cannot allocate the read buffers"); }
+    const bool can_stage = !c->host_pack && !getenv("F2Q_NO_STAGING");
+    if (can_stage && !c->copy_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming);
+        if (e != hipSuccess) { drop(); return fail(c, F2Q_EHIP, std::string("copy stream: ") + hipGetErrorString(e)); }
+    }
+    struct Piece { int slot; size_t n, a; uint64_t max_rec, first_read; bool ok; };
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Piece> ready; bool slot_free[NSLOT]; for (bool &f : slot_free) f = true; bool stop = false;
+    std::thread reader([&]() {
+        int slot = 0;
+        for (size_t j = 0; j <= jobs.size(); j++, slot = (slot + 1) % NSLOT) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot_free[slot] || stop; }); if (stop) return; slot_free[slot] = false; }
+            Piece pc{slot, 0, 0, 0, 0, true};
+            if (j < jobs.size()) {
+                const Job &jb = jobs[j];
+                const PieceSpan sp = piece_span(src.file_size, piece_bytes, jb.k);
+                const uint64_t want = std::min<uint64_t>(sp.size + MARGIN, src.file_size - sp.base);
+                uint8_t *p = buf[slot].p + HEAD;
+                const size_t n = src.read_at(sp.base, p, (size_t)want);
+                pc.ok = n == want;
+                // the first record start: the line after the one cut by the piece's start, then `skip_lines` more
+                size_t a = 0;
+                uint64_t skip = jb.skip_lines + (jb.at_line_start ? 0 : 1);
+                while (skip && a < n) { const uint8_t *q = (const uint8_t *)memchr(p + a, 0x0a, n - a); if (!q) { a = n; break; } a = (size_t)(q - p) + 1; skip--; }
+                // the margin must hold the rest of the last record (4 more newlines, or the end of the file)
+                if (sp.base + want < src.file_size) {
+                    size_t seen = 0, o = (size_t)sp.size;
+                    while (seen < 4 && o < n) { const uint8_t *q = (const uint8_t *)memchr(p + o, 0x0a, n - o); if (!q) break; o = (size_t)(q - p) + 1; seen++; }
+                    if (seen < 4) pc.ok = false;           // lines too long for the margin: the caller falls back
+                }
+                pc.n = n; pc.a = a; pc.max_rec = jb.n_records; pc.first_read = jb.first_read;
+            }
+            { std::lock_guard<std::mutex> g(mu); ready.push_back(pc); }
+            cv.notify_all();
+        }
+    });
+    struct Staged { void *buf = nullptr; size_t cap = 0; int slot = -1; size_t n = 0; } staged;
+    auto unstage = [&]() {
+        if (!staged.buf) return;
+        (void)hipStreamSynchronize(c->copy_stream);
+        std::vector<void *> v{staged.buf}; free_all(c, v);
+        staged = Staged();
+    };
+    auto stage_next = [&]() {
+        if (!can_stage || staged.buf) return;
+        Piece nx{-1, 0, 0, 0, 0, true};
+        { std::unique_lock<std::mutex> lk(mu); if (!ready.empty()) nx = ready.front(); }
+        if (nx.slot < 0 || nx.n == 0 || !nx.ok) return;
+        void *d = nullptr;
+        const size_t dcap = HEAD + nx.n + 2 * (size_t)F2Q_NL_CHUNK + 64;
+        if (dev_get(c, dcap, &d) != F2Q_OK) return;
+        if (hipMemcpyAsync((uint8_t *)d + HEAD, buf[nx.slot].p + HEAD, nx.n, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+            hipEventRecord(c->ev_copy, c->copy_stream) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream);
+            std::vector<void *> v{d}; free_all(c, v);
+            return;
+        }
+        staged.buf = d; staged.cap = dcap; staged.slot = nx.slot; staged.n = nx.n;
+    };
+    f2q_timing sum; memset(&sum, 0, sizeof sum);
+    int rc = F2Q_OK;
+    for (size_t j = 0; j <= jobs.size(); j++) {
+        Piece pc;
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !ready.empty(); }); pc = ready.front(); ready.pop_front(); }
+        Staged mine;
+        if (staged.buf && staged.slot == pc.slot && staged.n == pc.n) {
+            mine = staged; staged = Staged();
+            if (hipStreamWaitEvent(c->stream, c->ev_copy, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); }
+        } else unstage();
+        if (j < jobs.size()) stage_next();
+        if (!pc.ok) rc = fail(c, F2Q_EUNSUPPORTED, "a line longer than the piece margin (or a short read): count this file unsharded");
+        if (!rc && j < jobs.size() && pc.n > pc.a) {
+            f2q_timing one; memset(&one, 0, sizeof one);
+            size_t used = 0;
+            c->reads_seen = pc.first_read;
+            uint8_t *base = buf[pc.slot].p + HEAD + pc.a;
+            if (mine.buf) {
+                // the text starts `a` bytes into the staged copy; the bytes between the 16-byte boundary below it and the
+                // text lengthen the first line, a header line, which is never looked at (fast2q.py:324-328)
+                const size_t textoff = HEAD + pc.a, al = textoff & ~(size_t)15, lead = textoff - al;
+                uint8_t *d = (uint8_t *)mine.buf;
+                hipError_t e = lead ? hipMemsetAsync(d + al, 'x', lead, c->stream) : hipSuccess;
+                if (e != hipSuccess) { rc = fail(c, F2Q_EHIP, hipGetErrorString(e)); }
+                else {
+                    DevText pre; pre.buf = mine.buf; pre.cap = mine.cap; pre.text = d + al; pre.last_byte = base[pc.n - pc.a - 1];
+                    rc = count_window(c, nullptr, lead + (pc.n - pc.a), &pre, &used, &one, pc.max_rec);   // the buffer now belongs to the block
+                    mine = Staged();
+                }
+            } else rc = count_window(c, base, pc.n - pc.a, nullptr, &used, &one, pc.max_rec);
+            sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
+            sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
+        }
+        if (mine.buf) { (void)hipStreamSynchronize(c->stream); std::vector<void *> v{mine.buf}; free_all(c, v); }
+        { std::lock_guard<std::mutex> g(mu); slot_free[pc.slot] = true; if (rc) stop = true; }
+        cv.notify_all();
+        if (rc) break;
+    }
+    unstage();
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv.notify_all();
+    reader.join();
+    drop();
+    if (t) *t = sum;
+    return rc;
 }
 
 // ---- synthetic workload ---------------------------------------------------------------------------

@@ -118,6 +118,14 @@ struct TextSource {
         return n;
     }
 
+    // plain regular files: up to `cap` bytes starting at byte `off` (parallel pread); short only at the end of the file
+    size_t read_at(uint64_t off, uint8_t *dst, size_t cap)
+    {
+        if (kind != PLAIN || !regular) return 0;
+        file_pos = off;
+        return read_plain(dst, cap);
+    }
+
 private:
     // continue (or start) as ordinary gzip from compressed offset `from`
     int open_gzip(uint64_t from, std::string &err)

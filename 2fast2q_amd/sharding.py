@@ -89,8 +89,33 @@ def iter_record_blocks(path, block_bytes=BLOCK_BYTES):
         yield 0, 0, b"", True
 
 
+PIECE_BYTES = 256 << 20
+
+
 def count_file_sharded(ctx, path, w, block_bytes=BLOCK_BYTES):
     """rank w.rank counts its blocks of `path` into ctx; returns the truncated-gzip flag"""
+    if hasattr(ctx, "count_pieces"):
+        # plain files: every rank reads only its own pieces.  The 4-line framing is global, so the ranks first pool the
+        # line counts of their pieces (one small all-reduce), then each frames its share on its own (include/f2q.h)
+        piece = int(os.environ.get("F2Q_PIECE_BYTES", PIECE_BYTES))
+        n_pieces, ok = ctx.file_pieces(path, piece)
+        if ok and n_pieces >= 1:
+            import torch
+            import torch.distributed as dist
+            census = torch.from_numpy(ctx.census_pieces(path, w.rank, w.size, piece, n_pieces).astype("int64"))
+            if w.backend == "nccl":
+                census = census.cuda()
+            dist.all_reduce(census)
+            try:
+                ctx.count_pieces(path, w.rank, w.size, piece, census.cpu().numpy().astype("uint64"))
+                failed = 0
+            except Exception:                       # a line longer than the look-ahead behind a piece
+                failed = 1
+            flag = torch.tensor([failed], dtype=torch.int64, device=census.device)
+            dist.all_reduce(flag)
+            if int(flag.item()) == 0:
+                return False
+            ctx.reset()                            # somebody could not: all ranks take the streaming path below
     if hasattr(ctx, "count_file_shard"):           # the library streams, frames and deals the pieces itself
         return ctx.count_file_shard(path, w.rank, w.size)[1]
     truncated = False                              # contexts without it (the CPU test-suite's stand-in): Python framing

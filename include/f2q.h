@@ -136,6 +136,21 @@ int f2q_count_file(f2q_ctx *ctx, const char *path, f2q_timing *t);
  * The sum over the ranks of counts and stats equals f2q_count_file's. */
 int f2q_count_file_shard(f2q_ctx *ctx, const char *path, uint32_t rank, uint32_t world, f2q_timing *t);
 
+/* The same job without any rank reading another rank's bytes (plain, regular files): the file is cut into pieces of
+ * piece_bytes (>= 4096), piece k belongs to rank k % world.  The 4-line framing is global, so the ranks first exchange
+ * how many lines each piece holds:
+ *   1. f2q_file_pieces   -- number of pieces; *shardable = 0 for gzip/BGZF/pipes (use f2q_count_file_shard there)
+ *   2. f2q_census_pieces -- census[2k] = newlines of piece k, census[2k+1] = 1 if it ends with one, for THIS rank's pieces
+ *                           (the other entries are left as they are: pass a zeroed vector)
+ *   3. the caller sums the census vectors over the ranks (one all-reduce of 2 * n_pieces uint64)
+ *   4. f2q_count_pieces  -- counts the records whose first line starts in this rank's pieces (global read indices)
+ * F2Q_EUNSUPPORTED from step 4: a line longer than the 1 MiB look-ahead behind a piece; nothing usable was counted on
+ * this rank -- reset and use f2q_count_file_shard.  Errors of the two context-free calls: f2q_last_error(NULL). */
+int f2q_file_pieces(const char *path, uint64_t piece_bytes, uint64_t *n_pieces, int *shardable);
+int f2q_census_pieces(const char *path, uint32_t rank, uint32_t world, uint64_t piece_bytes, uint64_t *census, uint64_t n_pieces);
+int f2q_count_pieces(f2q_ctx *ctx, const char *path, uint32_t rank, uint32_t world, uint64_t piece_bytes,
+                     const uint64_t *census, uint64_t n_pieces, f2q_timing *t);
+
 /* Device-resident blocks: the roofline entry points.  f2q_synth_create generates the §8(d)
  * reads on the device straight into the packed tile layout; f2q_block_from_fastq packs a host
  * FASTQ buffer the same way f2q_count_block does but keeps it resident; f2q_count_resident runs

@@ -32,3 +32,34 @@ A=$(find $W/one -name "one.csv" | head -1); B=$(find $W/two -name "two.csv" | he
 if [ -n "$A" ] && [ -n "$B" ] && cmp $A $B; then echo "compiled tables identical: $(wc -l < $A) rows" | tee -a $O/progress.txt; else echo "compiled tables differ or missing: [$A] [$B]" | tee -a $O/progress.txt; tail -30 $O/rank0.log; tail -30 $O/rank1.log; fi
 for s in s0 s1 s2; do a=$(find $W/one -name "${s}_reads.csv" | head -1); b=$(find $W/two -name "${s}_reads.csv" | head -1); [ -n "$a" ] && [ -n "$b" ] && tail -n +2 $a | cmp - <(tail -n +2 $b) && echo "$s reads table identical" | tee -a $O/progress.txt; done
 true
+# the same two ranks on one large plain file: every rank reads only its own pieces (f2q_count_pieces); wall time of
+# one process against two on the ONE GPU (a functional rehearsal: two ranks share one PCIe link and one device here)
+python - "$W" <<'PY'
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import importlib
+pkg = importlib.import_module("2fast2q_amd")
+w = sys.argv[1]
+import os
+os.makedirs(w + "/big")
+guides = [l.split(",")[1].strip() for l in open(w + "/g.csv")]
+with pkg.Counter(features=guides, miss=1) as c:
+    fq = bytes(c.synth_fastq(seed=5, n_reads=3_000_000, read_len=150))
+open(w + "/big/big.fastq", "wb").write(fq)
+PY
+export F2Q_PIECE_BYTES=67108864
+unset F2Q_FILE_CHUNK
+t0=$(date +%s%N)
+timeout -s ABRT -k 5 120 python -m 2fast2q_amd -c --s $W/big --g $W/g.csv --o $W/bone --fn one --m 1 --pb > $O/big_one.log 2>&1
+t1=$(date +%s%N); echo "one process: $(( (t1 - t0) / 1000000 )) ms wall (python start-up included)" > $O/time_one.txt
+for r in 0 1; do
+  RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29522 F2Q_DEVICE=0 F2Q_DIST_BACKEND=gloo \
+    timeout -s ABRT -k 5 120 python -m 2fast2q_amd -c --s $W/big --g $W/g.csv --o $W/btwo --fn two --m 1 --pb > $O/big_rank$r.log 2>&1 &
+done
+t0=$(date +%s%N); wait; t1=$(date +%s%N)
+echo "two ranks: $(( (t1 - t0) / 1000000 )) ms wall (python start-up, torch import and gloo rendezvous included)" > $O/time_two.txt
+cat $O/time_one.txt $O/time_two.txt | tee -a $O/progress.txt
+grep -h "Sample big was processed" $O/big_one.log $O/big_rank0.log $O/big_rank1.log | tee -a $O/progress.txt
+A=$(find $W/bone -name "one.csv" | head -1); B=$(find $W/btwo -name "two.csv" | head -1)
+if [ -n "$A" ] && [ -n "$B" ] && cmp $A $B; then echo "big file: compiled tables identical ($(wc -l < $A) rows), each rank read only its own pieces" | tee -a $O/progress.txt; else echo "big file: tables differ or missing [$A] [$B]" | tee -a $O/progress.txt; tail -20 $O/big_rank0.log; fi
+true

@@ -139,6 +139,58 @@ def test_count_file_shard_sums_to_the_whole(tmp_path, monkeypatch, kind, world):
             assert [(k, n) for k, n, _ in sharding.merge_ec_tables(tables)] == list(zip(orc.keys(), orc.counts()))
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+@pytest.mark.parametrize("piece", [4096, 50000, 1 << 20])
+def test_count_pieces_without_foreign_bytes(tmp_path, world, piece):
+    """f2q_file_pieces / f2q_census_pieces / f2q_count_pieces: every rank counts the newlines of its own pieces, the
+    census vectors are summed (here: in this process; in a run: one all-reduce), and each rank frames and counts the
+    records that start in its pieces.  The rank results add up to the oracle's on a file with CRLF lines, lines that
+    straddle pieces, a partial last record -- for Counter mode and for Extract+Count (keys merged by first read)."""
+    sharding = importlib.import_module("2fast2q_amd.sharding")
+    guides = synth.make_library(150, 20, 5)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=33, n_reads=9000, read_len=101), guides), 3, rate=0.004)
+    fq = fq.replace(b"\n", b"\r\n", 500) + b"@tail\nACGT"
+    path = tmp_path / "s.fastq"
+    path.write_bytes(fq)
+    for kw in (dict(miss=1), dict(mode="EC", upstream="ACGT", length=9)):
+        feats = guides if "mode" not in kw else None
+        orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)] if feats else None, **kw)
+        orc.count_fastq(fq)
+        ctxs = [pkg().Counter(features=feats, **kw) for _ in range(world)]
+        n_pieces, ok = ctxs[0].file_pieces(str(path), piece)
+        assert ok and n_pieces == -(-len(fq) // piece)
+        census = sum(c.census_pieces(str(path), r, world, piece, n_pieces) for r, c in enumerate(ctxs))
+        assert int(census[0::2].sum()) == fq.count(b"\n")
+        tot_counts, tot_stats, tables, reads = None, [0] * 5, [], 0
+        for r, c in enumerate(ctxs):
+            t = c.count_pieces(str(path), r, world, piece, census)
+            counts, stats = c.read_counts()
+            reads += t["reads"]
+            tot_stats = [a + int(b) for a, b in zip(tot_stats, stats)]
+            if feats:
+                tot_counts = list(counts) if tot_counts is None else [a + b for a, b in zip(tot_counts, counts)]
+            else:
+                tables.append(c.ec_results())
+            c.close()
+        assert tot_stats == orc.stats() and reads == orc.stats()[0]
+        if feats:
+            assert tot_counts == orc.counts()
+        else:
+            assert [(k, n) for k, n, _ in sharding.merge_ec_tables(tables)] == list(zip(orc.keys(), orc.counts()))
+    gz = tmp_path / "s.fastq.gz"
+    gz.write_bytes(gzip.compress(fq, 1))
+    with pkg().Counter(features=guides) as c:
+        assert c.file_pieces(str(gz), piece) == (0, False)            # compressed input: the streaming shard path
+    # a line longer than the look-ahead behind a piece: refused (the caller falls back to f2q_count_file_shard)
+    long_line = tmp_path / "long.fastq"
+    long_line.write_bytes(b"@r\n" + b"A" * (3 << 20) + b"\n+\n" + b"I" * (3 << 20) + b"\n" + fq)
+    with pkg().Counter(features=guides, miss=1) as c:
+        n_p, ok = c.file_pieces(str(long_line), 1 << 20)
+        cen = c.census_pieces(str(long_line), 0, 1, 1 << 20, n_p)
+        with pytest.raises(pkg().F2QError):
+            c.count_pieces(str(long_line), 0, 1, 1 << 20, cen)
+
+
 def _output_cases():
     from test_abi_and_host import _golden_compiling_cases
     return _golden_compiling_cases()[0]
