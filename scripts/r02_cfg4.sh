@@ -1,0 +1,8 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/r02_cfg4; mkdir -p $out
+run() { name=$1; wl=$2; shift; shift; timeout -k 10 300 env "$@" python bench.py --workload $wl --steps 10 --no-pmc --no-cpu-baseline --no-extras > $out/$name.json 2> $out/$name.err; python -c "import json; d=json.load(open('$out/$name.json')); print('$name', round(d['value']), 'Mreads/s kernel_ms', round(d['roofline']['kernel_ms'],3), 'frac', round(d['roofline']['frac'],3))"; }
+run cfg4 cfg4_50M_100k_m1 F2Q_X=1
+run cfg3_nolt cfg3_50M_10k_m1 F2Q_NO_LT=1
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config4 or device_synth or config3 or geometry" > $out/pytest.txt 2>&1 || { tail -20 $out/pytest.txt; exit 1; }
+tail -1 $out/pytest.txt
