@@ -831,7 +831,7 @@ F2Q_HD uint32_t fixed4_flags(const FixedGeom &g, const U4 (&q)[QR], int j)
         if (r < g.nq) {
             const uint32_t m = (r == 0) ? g.qm_first : (r == g.nq - 1) ? g.qm_last : 0x80808080u;
             const uint32_t f = (u4get(q[r], j) & m) >> 7;                       // 0/1 at bits 0, 8, 16, 24
-            bits |= (uint64_t)(((f * 0x00204081u) >> 21) & 0xFu) << (4 * r);    // gathered into a nibble
+            bits |= (uint64_t)((f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu) << (4 * r);   // gathered into a nibble (no multiply: v_mul_lo_u32 is quarter rate)
         }
     }
     return (uint32_t)(bits >> (g.st & 3));
@@ -962,6 +962,14 @@ F2Q_HD uint32_t ham2_32(uint32_t x) {
     return (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
 #else
     return (uint32_t)__builtin_popcount((x | (x >> 1)) & 0x55555555u);
+#endif
+}
+F2Q_HD uint32_t lt_ctz(uint32_t x)            // index of the lowest set bit (x != 0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(__ffs((int)x) - 1);
+#else
+    return (uint32_t)__builtin_ctz(x);
 #endif
 }
 F2Q_HD uint32_t spread16(uint32_t v)          // bit i -> bit 2i, i < 16
@@ -1096,8 +1104,11 @@ F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4],
     const LtSide a = lt_side(w0, w1, 1u << lt.hb1, q.b[0], q.b[1], e[0], e[1]);
     LtSide b = a;
     uint32_t w2 = 0, w3 = 0;
-    LtPred fast = LT_P(forced == 0u) & LT_NOT(a.multi);
-    LtPred perfect = fast & a.any & LT_P(a.x == 0u), near = perfect & LT_NOT(perfect);      // near = false
+    const LtPred unforced = LT_P(forced == 0u);
+    // fast: at most one entry per table has the query's half.  Without NEAR a flagged read can match nothing.
+    LtPred fast = LT_NOT(a.multi);
+    if (!NEAR) fast = fast & unforced;
+    LtPred perfect = unforced & fast & a.any & LT_P(a.x == 0u), near = perfect & LT_NOT(perfect);      // near = false
     uint32_t slot = a.slot;
     if (NEAR) {
         w2 = lt_tag(q.cmp[2], q.h0, lt.hb0); w3 = lt_tag(q.cmp[3], q.h0, lt.hb0);
@@ -1105,11 +1116,30 @@ F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4],
         fast = fast & LT_NOT(b.multi);
         perfect = perfect & fast;
         const LtPred c0 = a.any & LT_P(ham2_32(a.x) == 1u), c1 = b.any & LT_P(ham2_32(b.x) == 1u);
-        near = fast & LT_NOT(perfect) & (c0 ^ c1);            // exactly one feature at distance 1
-        const LtPred via1 = near & c1;
+        near = unforced & fast & LT_NOT(perfect) & (c0 ^ c1);            // exactly one feature at distance 1
+        LtPred via1 = near & c1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool some_forced = LT_NOT(unforced) != 0ull;               // wave-uniform: most tiles skip this
+#else
+        const bool some_forced = forced != 0u;
+#endif
+        if (some_forced) {
+            // ONE flagged base (a forced mismatch): the candidates are the
+            // entries of the table bucketed by the CLEAN half whose other half agrees everywhere but at the flagged
+            // base -- with at most one entry of the query's half per table (fast) that is one mask and one compare
+            const uint32_t l0 = lt.hb0 >> 1;
+            const uint32_t p = forced ? lt_ctz(forced) : 0u;
+            const bool in0 = p < l0;                                      // flagged base in half 0: table 1 decides
+            const uint32_t keep = ~(3u << (2u * (in0 ? p : p - l0)));
+            const uint32_t xs = in0 ? b.x : a.x;
+            const LtPred one = LT_P((forced & (forced - 1u)) == 0u);      // two flagged bases are two mismatches: nothing within --m 1
+            const LtPred g = LT_NOT(unforced) & one & fast & LT_P((xs & keep) == 0u) & LT_P(in0 ? LT_TRUE(b.any) : LT_TRUE(a.any));
+            near = near | g;
+            via1 = via1 | (g & LT_P(in0));
+        }
         if (LT_TRUE(via1)) slot = lt_slot_of_t1(lt, q, b.x ^ LT_SEL(b.first, w2, w3), rd0);
     }
-    // flagged symbols, or several features sharing one of the query's halves: the general routine
+    // several features sharing one of the query's halves: the general routine
     int sres = 0;
     if (!LT_TRUE(fast)) {
         sres = R_NONALIGNED;
