@@ -94,6 +94,20 @@ struct LtDesc {
     const uint32_t *feat_of;           // [F2Q_LT_SLOTS] feature of a table-0 slot (unused slots: 0)
 };
 
+// "General keys": an index of ALL features as byte strings, by length -- what the byte-exact routine looks keys up in
+// that are no plain ACGT string of <= 31 bases (':'-joined multi-part keys, long features, odd symbols), and every key of
+// a run whose library holds such features.  Per length group an exact table (hash of all bytes) and m+1 pigeonhole
+// piece tables (hash of a byte range); entries are feature ids + 1, candidates are verified on the feature bytes.
+#define F2Q_GK_MAXP 8
+struct GkGroup {
+    uint32_t len, n, ids_off;          // feature length, features of that length, their ids at ids[ids_off ..]
+    uint32_t exact_off, bits;          // tables of 1 << bits slots at tab[exact_off], tab[piece_off[p]]
+    uint32_t n_pieces;                 // 0: no pigeonhole tables (--m 0, or fewer bytes than pieces: the group is scanned)
+    uint32_t piece_off[F2Q_GK_MAXP];
+    uint32_t cut[F2Q_GK_MAXP + 1];     // piece p = bytes [cut[p], cut[p+1])
+};
+struct GkDesc { uint32_t n_groups, pad; const GkGroup *grp; const uint32_t *tab; const uint32_t *ids; };
+
 // multi-window runs (--st a,b,...): a key is the ':'-joined windows that passed their Phred test (fast2q.py:349-363);
 // features made of k ACGT runs of --l bases joined by ':' ("k-part features") are indexed by their k*l bases
 #define F2Q_MW_MAX 4               // windows of a run the packed path handles (k * l <= 31 bases)
@@ -104,6 +118,7 @@ struct LibDev {
     PackedGroup mpk[F2Q_MW_MAX];       // multi-window runs: packed tables of the k-part features, k = index + 1 (len = k * l)
     uint32_t mw_ok, mw_pad;            // 1: every feature a multi-window key can equal or approach is a k-part feature
     LtDesc lt;
+    GkDesc gk;
     const uint64_t *tab_keys;          // open-addressing slots: 2-bit feature key or KEY_EMPTY
     const uint32_t *tab_idx;           // feature index of the slot
     const uint8_t *feat_bytes;         // all features, raw (upper-case) bytes
@@ -318,6 +333,77 @@ F2Q_HD void lib_scan(const LibDev &lib, const KV &kv, const uint32_t *ids_, uint
     }
 }
 
+// ---- general keys (GkDesc) ------------------------------------------------------------------------------------
+F2Q_HD uint64_t gk_mix(uint64_t h) { h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; return h; }
+// FNV-1a over bytes [a, b) of a feature / of a key (upper-cased, ':' between the segments), salted by the piece number
+template <class P>
+F2Q_HD uint64_t gk_hash_bytes(P fb, int a, int b, uint32_t salt)
+{
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)salt;
+    for (int k = a; k < b; k++) { h ^= fb[k]; h *= 1099511628211ull; }
+    return gk_mix(h);
+}
+template <class KV>
+F2Q_HD uint64_t gk_hash_key(const KV &kv, int a, int b, uint32_t salt)
+{
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)salt;
+    for (int k = a; k < b; k++) { h ^= kv.at(k); h *= 1099511628211ull; }
+    return gk_mix(h);
+}
+template <class KV>
+F2Q_HD bool gk_range_equal(const KV &kv, gbytes fb, int a, int b)
+{
+    for (int k = a; k < b; k++) if (kv.at(k) != fb[k]) return false;
+    return true;
+}
+F2Q_HD const GkGroup *gk_find(const LibDev &lib, int len)
+{
+    int lo = 0, hi = (int)lib.gk.n_groups - 1;                 // groups are sorted by length
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t l = lib.gk.grp[mid].len;
+        if ((int)l == len) return &lib.gk.grp[mid];
+        if ((int)l < len) lo = mid + 1; else hi = mid - 1;
+    }
+    return nullptr;
+}
+// exact hit among the features of the group: feature index or -1
+template <class KV>
+F2Q_HD int gk_exact(const LibDev &lib, const GkGroup &g, const KV &kv)
+{
+    const uint32_t m = (1u << g.bits) - 1u;
+    uint32_t s = (uint32_t)(gk_hash_key(kv, 0, kv.len, 0xE0u) >> (64u - g.bits));
+    const auto tab = gp(lib.gk.tab);
+    for (;;) {
+        const uint32_t e = tab[g.exact_off + s];
+        if (e == 0u) return -1;
+        if (gk_range_equal(kv, gp(lib.feat_bytes) + gp(lib.feat_off)[e - 1u], 0, kv.len)) return (int)(e - 1u);
+        s = (s + 1u) & m;
+    }
+}
+// pigeonhole search over the group (see lib_near): every feature within t.best of the key agrees with it on a whole piece
+template <class KV>
+F2Q_HD void gk_near(const LibDev &lib, const GkGroup &g, const KV &kv, MinTrack &t)
+{
+    const uint32_t m = (1u << g.bits) - 1u;
+    const auto tab = gp(lib.gk.tab);
+    for (uint32_t p = 0; p < g.n_pieces; p++) {
+        const int a = (int)g.cut[p], b = (int)g.cut[p + 1];
+        uint32_t s = (uint32_t)(gk_hash_key(kv, a, b, p) >> (64u - g.bits));
+        for (;;) {
+            const uint32_t e = tab[g.piece_off[p] + s];
+            if (e == 0u) break;
+            gbytes fb = gp(lib.feat_bytes) + gp(lib.feat_off)[e - 1u];
+            if (gk_range_equal(kv, fb, a, b)) {
+                bool dup = false;                              // counted at the first piece it agrees on
+                for (uint32_t q = 0; q < p && !dup; q++) dup = gk_range_equal(kv, fb, (int)g.cut[q], (int)g.cut[q + 1]);
+                if (!dup) { const int d = key_dist(kv, fb, t.best); if (d <= t.best) t.offer(d, e - 1u); }
+            }
+            s = (s + 1u) & m;
+        }
+    }
+}
+
 // Counter-mode decision for one extracted key: returns 1 perfect, 2 imperfect, 3 non-aligned,
 // and the feature index in `idx`.
 template <class KV>
@@ -335,17 +421,25 @@ F2Q_HD int match_key(const RunDev &run, const LibDev &lib, const KV &kv, uint32_
         }
     }
     MinTrack t; t.init(run.miss);
-    if (regular) {
+    if (regular && lib.n_irregular == 0) {
         if (nforced == 0) {
             int e = lib_exact(lib, key, kv.len);
             if (e >= 0) { idx = (uint32_t)e; return 1; }
         }
         // regular features: a non-ACGT query symbol mismatches every one of them
         if (run.miss > 0 && nforced <= run.miss) lib_near(lib, key, kv.len, forced, t);
-        // irregular features (non-ACGT symbols, or longer than 31) are compared byte-wise
-        if (lib.n_irregular && (run.miss > 0 || nforced > 0)) lib_scan(lib, kv, lib.irr_ids, lib.n_irregular, t);
     } else {
-        lib_scan(lib, kv, nullptr, lib.n_features, t);
+        // ':'-joined, long or odd-symbol keys, and every key once the library itself holds such features: the byte-string
+        // index over ALL features of the key's length (the reference compares with every same-length feature, :683)
+        const GkGroup *g = gk_find(lib, kv.len);
+        if (g) {
+            const int e = gk_exact(lib, *g, kv);
+            if (e >= 0) { idx = (uint32_t)e; return 1; }
+            if (run.miss > 0) {
+                if (g->n_pieces) gk_near(lib, *g, kv, t);
+                else lib_scan(lib, kv, lib.gk.ids + g->ids_off, g->n, t);   // fewer bytes than pieces: the whole group is within reach
+            }
+        }
     }
     if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? 1 : 2; }
     // best == 0 with cnt > 1 cannot happen (library sequences are unique)
@@ -705,23 +799,20 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
     if (L < 1) {
         // empty window: the key "" can only match an (irregular) empty feature
         KeyView kv; kv.seq = nullptr; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = 0; kv.len = 0;
-        MinTrack t; t.init(run.miss);
-        if (lib.n_irregular) lib_scan(lib, kv, lib.irr_ids, lib.n_irregular, t);
-        if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? 1 : 2; }
-        return 3;
+        return match_key(run, lib, kv, idx);
     }
-    int e = lib_exact(lib, key, L);
-    if (e >= 0) { idx = (uint32_t)e; return 1; }
-    if (run.miss == 0 && lib.n_irregular == 0) return 3;
-    MinTrack t; t.init(run.miss);
-    if (run.miss > 0) lib_near(lib, key, L, 0ull, t);
     if (lib.n_irregular) {
-        // decode the window for the byte-wise scan of irregular features
+        // a library that also holds odd symbols or other lengths: decode the window, the byte-string index decides
         uint8_t wbuf[F2Q_REG_MAXLEN + 1];
         for (int j = 0; j < L; j++) wbuf[j] = (uint8_t)"ACGT"[(key >> (2 * j)) & 3];
         KeyView kv; kv.seq = wbuf; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = L; kv.len = L;
-        lib_scan(lib, kv, lib.irr_ids, lib.n_irregular, t);
+        return match_key(run, lib, kv, idx);
     }
+    int e = lib_exact(lib, key, L);
+    if (e >= 0) { idx = (uint32_t)e; return 1; }
+    if (run.miss == 0) return 3;
+    MinTrack t; t.init(run.miss);
+    lib_near(lib, key, L, 0ull, t);
     if (t.cnt == 1) { idx = t.idx; return t.best == 0 ? 1 : 2; }
     return 3;
 }

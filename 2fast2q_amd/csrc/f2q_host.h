@@ -4,6 +4,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,9 @@ struct HostIndex {
     LtDesc lt{};
     std::vector<uint32_t> lt_tags, lt_feat_of;
     std::vector<uint16_t> lt_slot_of;
+    // general keys (GkDesc): byte-string index of all features by length
+    std::vector<GkGroup> gk_groups;
+    std::vector<uint32_t> gk_tab, gk_ids;
     LenGroup grp[F2Q_REG_MAXLEN + 1];
     uint32_t n_features = 0, n_irregular = 0;
 };
@@ -177,6 +181,51 @@ inline void build_lt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, i
     ix.lt = lt;
 }
 
+// byte-string index of ALL features, by length (f2q_device.h: GkDesc): exact table + m+1 pigeonhole piece tables per group
+inline void build_gk(HostIndex &ix, int miss)
+{
+    ix.gk_groups.clear(); ix.gk_tab.assign(1, 0u); ix.gk_ids.clear();
+    std::vector<uint32_t> order(ix.n_features);
+    for (uint32_t f = 0; f < ix.n_features; f++) order[f] = f;
+    auto flen = [&](uint32_t f) { return ix.feat_off[f + 1] - ix.feat_off[f]; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return flen(a) < flen(b); });
+    ix.gk_ids = order;
+    if (ix.gk_ids.empty()) ix.gk_ids.push_back(0);
+    for (size_t i = 0; i < order.size();) {
+        size_t j = i;
+        while (j < order.size() && flen(order[j]) == flen(order[i])) j++;
+        GkGroup g; memset(&g, 0, sizeof g);
+        g.len = flen(order[i]); g.n = (uint32_t)(j - i); g.ids_off = (uint32_t)i;
+        g.bits = 4; while ((1ull << g.bits) < 2ull * g.n) g.bits++;
+        const int P = miss > 0 ? miss + 1 : 0;
+        g.n_pieces = (P >= 1 && P <= F2Q_GK_MAXP && (uint32_t)P <= g.len) ? (uint32_t)P : 0u;
+        g.exact_off = (uint32_t)ix.gk_tab.size();
+        ix.gk_tab.resize(ix.gk_tab.size() + ((size_t)1 << g.bits), 0u);
+        for (uint32_t p = 0; p < g.n_pieces; p++) {
+            g.cut[p] = (uint32_t)((uint64_t)p * g.len / g.n_pieces);
+            g.piece_off[p] = (uint32_t)ix.gk_tab.size();
+            ix.gk_tab.resize(ix.gk_tab.size() + ((size_t)1 << g.bits), 0u);
+        }
+        g.cut[g.n_pieces] = g.len;
+        const uint32_t m = (1u << g.bits) - 1u;
+        for (size_t q = i; q < j; q++) {
+            const uint32_t f = order[q];
+            const uint8_t *fb = ix.feat_bytes.data() + ix.feat_off[f];
+            uint32_t s = (uint32_t)(gk_hash_bytes(fb, 0, (int)g.len, 0xE0u) >> (64u - g.bits));
+            while (ix.gk_tab[g.exact_off + s]) s = (s + 1u) & m;
+            ix.gk_tab[g.exact_off + s] = f + 1u;
+            for (uint32_t p = 0; p < g.n_pieces; p++) {
+                s = (uint32_t)(gk_hash_bytes(fb, (int)g.cut[p], (int)g.cut[p + 1], p) >> (64u - g.bits));
+                while (ix.gk_tab[g.piece_off[p] + s]) s = (s + 1u) & m;
+                ix.gk_tab[g.piece_off[p] + s] = f + 1u;
+            }
+        }
+        ix.gk_groups.push_back(g);
+        i = j;
+    }
+    if (ix.gk_groups.empty()) { GkGroup g; memset(&g, 0, sizeof g); g.len = 0xFFFFFFFFu; ix.gk_groups.push_back(g); }
+}
+
 // packed_len: the feature length the packed tables index (the window length of a fixed-offset run); mw_windows >= 2:
 // a multi-window run of that many windows, whose k-part features get packed tables of their own
 inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss, int packed_len = 0, int mw_windows = 0)
@@ -257,6 +306,7 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
         ix.mw_ok = mw_ok ? 1u : 0u;
     }
     build_lt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss);
+    build_gk(ix, miss);
     ix.n_irregular = (uint32_t)ix.irr_ids.size();
     if (ix.irr_ids.empty()) ix.irr_ids.push_back(0);     // keep the device array non-empty
 }

@@ -228,6 +228,11 @@ static int upload_lib(f2q_ctx *c)
         if ((rc = dev_upload(c, c->ix.lt_feat_of.data(), c->ix.lt_feat_of.size(), &lt_feat, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.lt_slot_of.data(), c->ix.lt_slot_of.size(), &lt_slot, c->lib_allocs))) return rc;
         L.lt = c->ix.lt; L.lt.tags = lt_tags; L.lt.feat_of = lt_feat; L.lt.slot_of = lt_slot;
+        GkGroup *gk_grp; uint32_t *gk_tab, *gk_ids;
+        if ((rc = dev_upload(c, c->ix.gk_groups.data(), c->ix.gk_groups.size(), &gk_grp, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.gk_tab.data(), c->ix.gk_tab.size(), &gk_tab, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.gk_ids.data(), c->ix.gk_ids.size(), &gk_ids, c->lib_allocs))) return rc;
+        L.gk.n_groups = c->ix.n_features ? (uint32_t)c->ix.gk_groups.size() : 0u; L.gk.grp = gk_grp; L.gk.tab = gk_tab; L.gk.ids = gk_ids;
     }
     L.tab_keys = tk; L.tab_idx = ti; L.feat_bytes = fb; L.feat_off = fo; L.irr_ids = ir;
     c->guide_keys_d = gk;

@@ -38,6 +38,8 @@ static void bind_lib(Emu *e)
     L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
     L.lt = e->ix.lt; L.lt.tags = e->ix.lt_tags.data(); L.lt.slot_of = e->ix.lt_slot_of.data();
     L.lt.feat_of = e->ix.lt_feat_of.data();
+    L.gk.n_groups = e->ix.n_features ? (uint32_t)e->ix.gk_groups.size() : 0u; L.gk.grp = e->ix.gk_groups.data();
+    L.gk.tab = e->ix.gk_tab.data(); L.gk.ids = e->ix.gk_ids.data();
     memcpy(L.grp, e->ix.grp, sizeof L.grp);
     e->acc.assign(e->ix.n_features + 5, 0);
 }

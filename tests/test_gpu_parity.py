@@ -489,6 +489,23 @@ def test_multi_window_packed_kernel_vs_oracle(P, monkeypatch, miss, starts, leng
     assert t2["fast_reads"] == 0 and list(stats2) == list(stats) and list(counts2) == list(counts)
 
 
+@pytest.mark.parametrize("miss", [0, 1, 3])
+@pytest.mark.parametrize("glen", [12, 40])
+def test_general_key_index_kernel_vs_oracle(P, miss, glen):
+    """k_count_general over the byte-string index (GkDesc): a library with odd symbols, three lengths and near-duplicates,
+    and 40-base windows that no 2-bit table holds"""
+    from test_lane_logic_cpu import general_key_case
+    lib, fq = general_key_case(miss, glen, n=4000, n_reads=30000)
+    kw = dict(miss=miss, length=glen, start="6")
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    with P.Counter(features=lib, **kw) as c:
+        c.count_block(fq)
+        counts, stats = c.read_counts()
+    assert list(stats) == o.stats() and list(counts) == o.counts()
+    assert stats[1] > 0 and (miss == 0 or stats[2] > 0)
+
+
 def test_two_window_full_size(P, monkeypatch):
     """50M reads, two 10-base windows (--st 0,10 --l 10) against 10k two-part features: the packed multi-window kernel
     against the single-window run of the 20-base form of the same library on the same reads (same counts: see below),

@@ -218,6 +218,35 @@ def test_odd_symbols_in_the_window(miss):
             assert (gen == 0) == (lib is guides)
 
 
+def general_key_case(miss, glen, n=160, n_reads=2000):
+    base = synth.make_library(n, glen, 77 + glen)
+    a, b, c = n * 5 // 8, n * 13 // 16, n * 29 // 32
+    lib = list(base[:a])
+    lib += [g[:3] + "N" + g[4:] for g in base[a:b]]                      # odd symbol: an irregular feature
+    lib += [base[0][:glen - 1] + ch for ch in "CGT" if base[0][:glen - 1] + ch not in lib]   # near-duplicates -> ties
+    lib += sorted({g[:glen - 2] for g in base[b:c]})                    # shorter features
+    lib += [g + "AC" for g in base[c:]]                                  # longer features
+    spec = synth.Spec(seed=miss + glen, n_reads=n_reads, read_len=glen + 12, start=6, p_sub=0.35, p_rand=0.1, p_n=0.05)
+    return lib, sprinkle_symbols(synth.make_fastq(spec, base), 5)
+
+
+@pytest.mark.parametrize("miss", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("glen", [12, 40])
+def test_general_key_index_vs_oracle(miss, glen):
+    """the byte-string index (GkDesc: exact table + miss+1 piece tables per feature length) that serves every key the
+    2-bit tables cannot: libraries holding odd symbols or several lengths, and windows longer than 31 bases.  Shared
+    prefixes make long probe chains and ties; features of other lengths must never be candidates (fast2q.py:683)."""
+    lib, fq = general_key_case(miss, glen)
+    kw = dict(miss=miss, length=glen, start="6")
+    o = O.Oracle(features=[(f"g{i}", s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    e = Emu(features=lib, **kw)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats() and counts == o.counts()
+    assert gen > 0 and (glen <= 31 or gen == stats[0]) and stats[1] > 0 and (miss == 0 or stats[2] > 0)
+
+
 UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
 
 
