@@ -867,15 +867,17 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 // Counter mode, all-ACGT library of <= 31-base features (the packed path's precondition): an empty
                 // or longer window passed its Phred test but can equal or approach no feature (:683) -> not aligned
                 st[3]++; st[0]++;
-            } else if (aw.ok == 1 && EC && L > F2Q_EC64_MAXLEN) {
-                // Extract+Count key too long for the single-word table: decode the window and use the byte-string table
+            } else if (aw.ok == 1 && EC && (L > F2Q_EC64_MAXLEN || (flagged && L > 0 && !ec64_fits(plane_extract<NW>(FLG, aw.start, L), L)))) {
+                // Extract+Count key the single-word table cannot hold (too long, or it spells an 'N'): decode the window
+                // and use the byte-string table
                 uint8_t kb[32 * NW];
 #pragma unroll
                 for (int cw = 0; cw < NW; cw++) {
                     const int off = 32 * cw, n = L - off < 32 ? L - off : 32;
                     if (n > 0) {
                         const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
-                        for (int j = 0; j < n; j++) kb[off + j] = (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
+                        const uint32_t fl = plane_extract<NW>(FLG, aw.start + off, n);
+                        for (int j = 0; j < n; j++) kb[off + j] = ((fl >> j) & 1u) ? (uint8_t)'N' : (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
                     }
                 }
                 KeyView kv; kv.seq = kb; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = L; kv.len = L;
@@ -892,9 +894,10 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 // the window itself holds non-ACGT symbols
                 st[0]++;
                 const uint32_t forced = plane_extract<NW>(FLG, aw.start, L);
-                if (EC) {
-                    // unreachable: Extract+Count keys hold the symbol itself, so the packer never flags reads in EC runs
-                    st[3]++;
+                if (EC) {                          // an 'N' in the window, and the key has a single-word form
+                    unsigned long long w = 0;
+                    ec64_word(plane_key<NW>(LO, HI, aw.start, L), forced, L, w);
+                    n_new += ec64_insert_word(ec, w, gi); st[1]++;
                 } else if (!do_near || __popc(forced) > run.miss) st[3]++;
                 else {
                     const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
@@ -908,7 +911,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
             } else {
                 const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
                 st[0]++;
-                if (EC) { n_new += ec64_insert_n(ec, key, L, gi); st[1]++; }
+                if (EC) { n_new += ec64_insert_n(ec, key, L, gi); st[1]++; }   // (no flagged base in the window)
                 else if (L == pk_len) {
                     const int e = packed_exact(lib, key);
                     if (e >= 0) { count_hit((uint32_t)e); st[1]++; }
@@ -1123,6 +1126,339 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_count_anchor_lt(const RunDe
     flush_stats(acc, stv, reinterpret_cast<unsigned long long *>(lt_smem), acc.stat_slab + (uint64_t)blockIdx.x * 8u);
 }
 
+// ---- anchored Extract+Count with the hot keys in LDS (EcHot, f2q_device.h) ------------------------------------------
+// k_count_anchor_lt's tile walk and extraction stage; the key of a passing window is looked up in the workgroup's copy
+// of the hot-key tags (two buckets, 2 x ds_read_b128), a tag hit is verified against the full key in global memory
+// (16 bytes, L2) and counted in an LDS counter; everything else takes the single-word table's insert.  Reads the
+// single-word table cannot hold (window over 29 bases, negative-index slices) are only noted in `defer`: the host
+// sizes the byte-string table for exactly those and k_ec_deferred decides them with the byte-exact routine.
+// The packer never flags reads of an Extract+Count run (the key holds the symbol itself), so there are no flag planes.
+__device__ __forceinline__ U4 lds_u4(const uint32_t *p)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 v = *reinterpret_cast<const v4 *>(p);              // ds_read_b128
+    return U4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ uint32_t hot_match(const U4 &t, uint32_t tag, uint32_t bucket)
+{
+    return t.x == tag ? 4u * bucket : t.y == tag ? 4u * bucket + 1u : t.z == tag ? 4u * bucket + 2u : t.w == tag ? 4u * bucket + 3u : F2Q_HOT_NONE;
+}
+
+// an entry of the list of reads set aside: slot of the view, kind (1: byte-exact routine), window start and length
+#define F2Q_DEFER_SLOW 0x80000000ull
+#define F2Q_DEFER_FLAGS 0x40000000ull   // the read holds flagged bases ('N')
+__device__ __forceinline__ unsigned long long defer_entry(uint64_t slot, bool slow, int start, int L)
+{
+    return ((unsigned long long)slot << 32) | (slow ? F2Q_DEFER_SLOW : 0ull) | ((unsigned long long)(start & 0x3FFF) << 16) | (unsigned long long)(L & 0xFFFF);
+}
+
+template <int NW, int KB, bool SAMEQ>
+__global__ __launch_bounds__(F2Q_ALT_THREADS) void k_extract_anchor_hot(const RunDev *__restrict__ runp, EcDev ec, EcHot hot,
+                                                                       PackedBlock pb, Accum acc, uint64_t read_base,
+                                                                       unsigned long long *__restrict__ defer, int learning)
+{
+    // (defer has room for every slot of the view; an index past it would be a logic error and is reported, not written)
+    unsigned long long *const defer_n = ec.ctr + F2Q_CTR_ASIDE;
+    constexpr int NQW = 8 * NW;
+    extern __shared__ uint32_t hot_smem[];
+    uint32_t *tg = hot_smem;                                    // [F2Q_HOT_SLOTS] tags
+    uint32_t *cnt = hot_smem + F2Q_HOT_SLOTS;                   // [F2Q_HOT_SLOTS] hits of this workgroup
+    const RunDev &run = *runp;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, slot_in_tile = tid & (F2Q_TILE - 1u), group = tid / F2Q_TILE;
+    {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(hot.tags);
+        v4 *dst = reinterpret_cast<v4 *>(tg);
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 4u; i += F2Q_ALT_THREADS) dst[i] = src[i];
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_ALT_THREADS) cnt[i] = 0;
+    }
+    __syncthreads();
+    const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
+    uint32_t w_reads = 0, w_pass = 0, w_qfail = 0;              // this wave's counters (scalar registers)
+    uint32_t n_new = 0;
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 F2Q_GLOBAL *kf = (const v2u64 F2Q_GLOBAL *)gp(hot.kf);
+
+    struct Planes { uint32_t lo[NW], hi[NW], q[NQW], len; };
+    const auto b_base = gp(pb.bases) + slot_in_tile, q_base = gp(pb.qual) + slot_in_tile;
+    const auto l_base = gp(pb.len) + slot_in_tile;
+    const uint64_t b_stride = (uint64_t)pb.wb * F2Q_TILE, q_stride = (uint64_t)pb.wq * F2Q_TILE;
+    auto request_tile = [&](Planes &p, uint32_t t) {
+        const auto bp = b_base + (uint64_t)t * b_stride, qp = q_base + (uint64_t)t * q_stride;
+        p.len = l_base[(uint64_t)t * F2Q_TILE];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            p.lo[w] = __builtin_nontemporal_load(bp + (uint64_t)w * F2Q_TILE);
+            p.hi[w] = __builtin_nontemporal_load(bp + (uint64_t)(NW + w) * F2Q_TILE);
+        }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) p.q[i] = __builtin_nontemporal_load(qp + (uint64_t)i * F2Q_TILE);
+    };
+    // append the lanes of `m` to the list (rare: one counter bump per wave)
+    auto set_aside = [&](unsigned long long m, bool mine, unsigned long long entry) {
+        unsigned long long at = 0;
+        const int first = __builtin_ctzll(m);
+        if (lane == (uint32_t)first) at = ec_fetch_add(defer_n, (unsigned long long)__popcll(m));
+        at = __shfl(at, first, 64);
+        const unsigned long long di = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (mine && di < pb.n_slots) gpw(defer)[di] = entry;
+        else if (mine) F2Q_ST64(&ec.ctr[2], 7ull);
+    };
+    auto decide_tile = [&](const Planes &p, uint32_t tile) {
+        const uint32_t l = p.len;
+        uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW], FLG[NW];
+        const bool live = l != F2Q_LEN_SKIP;
+        const bool flagged = live && (l & F2Q_LEN_FLAG);       // the read holds 'N's (flag bits in the quality bytes)
+        if (__ballot(flagged) == 0ull) {              // the usual tile: no flag bits to strip, no flag planes to build
+#pragma unroll
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q8[i] = p.q[8 * cw + i];
+                FW[cw] = fail_word8<false>(q8, ah_w);
+                if (!SAMEQ) { FU[cw] = fail_word8<false>(q8, ah_u); FD[cw] = fail_word8<false>(q8, ah_d); }
+                FLG[cw] = 0u;
+            }
+        } else {
+#pragma unroll
+            for (int cw = 0; cw < NW; cw++) {
+                uint32_t q8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q8[i] = p.q[8 * cw + i];
+                FW[cw] = fail_word8(q8, ah_w);
+                if (!SAMEQ) { FU[cw] = fail_word8(q8, ah_u); FD[cw] = fail_word8(q8, ah_d); }
+                FLG[cw] = flagged ? flag_word8(q8) : 0u;
+            }
+        }
+        const int r = (int)(l & 0x7FFFu);
+        AnchorWin aw;
+        if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FW, FW, FW);
+        else aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FU, FD, FW);
+        const int L = aw.end - aw.start;
+        const bool qf = live && aw.ok == 0;
+        const bool pass = live && aw.ok == 1;
+        const bool slow = live && aw.ok == 2;                   // negative-index slices: byte-exact routine
+        // the key's single-word form; a window that has none (too long, too many 'N's) is set aside for the byte-string table
+        const int wl0 = (pass && L >= 0 && L <= F2Q_EC64_MAXLEN) ? L : 0, ws0 = (pass && L >= 0 && L <= F2Q_EC64_MAXLEN) ? aw.start : 0;
+        const uint32_t nmask = (flagged && wl0 > 0) ? plane_extract<NW>(FLG, ws0, wl0) : 0u;
+        unsigned long long k = 0;
+        const bool has_word = ec64_word(plane_key<NW>(p.lo, p.hi, ws0, wl0), nmask, wl0, k) && pass && L <= F2Q_EC64_MAXLEN;
+        const bool later = slow || (pass && !has_word);
+        const bool ins = pass && !later;
+        w_reads += (uint32_t)__popcll(__ballot(live && !later));
+        w_qfail += (uint32_t)__popcll(__ballot(qf));
+        w_pass += (uint32_t)__popcll(__ballot(ins));
+        const uint64_t slot = (uint64_t)tile * F2Q_TILE + slot_in_tile;
+        const unsigned long long lm = __ballot(later);
+        if (lm) {
+            set_aside(lm, later, defer_entry(slot, slow, aw.start, L) | (flagged ? F2Q_DEFER_FLAGS : 0ull));
+            const unsigned long long sm = __ballot(slow);
+            if (sm && lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(sm));
+        }
+        const HotProbe q = hot_probe(k);
+        const U4 t1 = lds_u4(tg + 4u * q.b1), t2 = lds_u4(tg + 4u * q.b2);
+        const uint32_t c1 = hot_match(t1, q.tag, q.b1), c2 = hot_match(t2, q.tag, q.b2);
+        uint32_t s = c1 != F2Q_HOT_NONE ? c1 : c2;
+        bool hit = false;
+        unsigned long long gi = 0;
+        if (ins) {
+            gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+            if (s != F2Q_HOT_NONE) {
+                v2u64 e = kf[s];
+                hit = e.x == k && gi >= e.y;
+                if (!hit && c1 != F2Q_HOT_NONE && c2 != F2Q_HOT_NONE) {     // another key with the same tag sat in bucket 1
+                    s = c2; e = kf[s];
+                    hit = e.x == k && gi >= e.y;
+                }
+            }
+        }
+        bool full = false;
+        if (hit) atomicAdd(&cnt[s], 1u);
+        else if (ins) {
+            uint32_t ts = 0; unsigned long long before = 0;
+            const uint32_t rr = ec64_try_insert(ec, k, gi, F2Q_HOT_MAXPROBE, ts, before);
+            full = rr == 2u;
+            n_new += rr & 1u;
+            if (learning && rr != 2u && before + 1ull == F2Q_HOT_MINCOUNT) {       // a few thousand times per sample
+                const unsigned long long at = ec_fetch_add(ec.ctr + F2Q_CTR_CAND, 1ull);
+                if (at < F2Q_HOT_CAND) gpw(hot.cand)[at] = ts;
+            }
+        }
+        const unsigned long long fm = __ballot(full);
+        if (fm) {                                               // the table is (nearly) full: decided after it has grown
+            set_aside(fm, full, defer_entry(slot, true, aw.start, L));
+            if (lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(fm));
+            w_reads -= (uint32_t)__popcll(fm); w_pass -= (uint32_t)__popcll(fm);
+        }
+    };
+
+    const uint32_t stride = gridDim.x * F2Q_ALT_GROUPS, last = pb.n_tiles - 1u;
+    uint32_t tile = blockIdx.x * F2Q_ALT_GROUPS + group;
+    {
+        Planes pa, pb2;
+        if (tile < pb.n_tiles) {
+            request_tile(pa, tile);
+            for (;;) {
+                __builtin_amdgcn_sched_barrier(0);
+                request_tile(pb2, min(tile + stride, last));
+                __builtin_amdgcn_sched_barrier(0);
+                decide_tile(pa, tile);
+                tile += stride;
+                if (tile >= pb.n_tiles) break;
+                __builtin_amdgcn_sched_barrier(0);
+                request_tile(pa, min(tile + stride, last));
+                __builtin_amdgcn_sched_barrier(0);
+                decide_tile(pb2, tile);
+                tile += stride;
+                if (tile >= pb.n_tiles) break;
+            }
+        }
+    }
+    ec64_report_new(ec, n_new);
+    __syncthreads();
+    for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_ALT_THREADS) {
+        const uint32_t n = cnt[i];
+        if (n) {
+            const uint32_t ts = gp(hot.slot)[i];
+            if (ts <= ec.k64_mask) ec_fetch_add(&ec.k64_count[ts], (unsigned long long)n);
+            else F2Q_ST64(&ec.ctr[2], 8ull);                     // a stale link: reported by the host, never written
+        }
+    }
+    __syncthreads();
+    unsigned long long stv[5] = {0, 0, 0, 0, 0};
+    if (lane == 0) { stv[0] = w_reads; stv[1] = w_pass; stv[3] = w_reads - w_pass - w_qfail; stv[4] = w_qfail; }
+    flush_stats(acc, stv, reinterpret_cast<unsigned long long *>(hot_smem), nullptr);
+}
+
+// key bytes read straight from the bit planes of a tile slot, 32 bases per pair of loads (ec_insert needs len,
+// key_hash() and key_word())
+struct PlaneKV {
+    const uint32_t F2Q_GLOBAL *bp;          // the slot's column of the tile's base planes
+    const uint32_t F2Q_GLOBAL *qp;          // ... of its quality planes (flag bits), or nullptr: the read has no flagged base
+    uint32_t nw;
+    int start, len;
+    __device__ uint32_t codes16(int from) const      // 16 bases from position `from` as 2-bit codes (LSB first)
+    {
+        const int w = from >> 5, sh = from & 31;
+        uint64_t lo = bp[(uint64_t)w * F2Q_TILE], hi = bp[(uint64_t)(nw + w) * F2Q_TILE];
+        if (sh > 16 && (uint32_t)(w + 1) < nw) {
+            lo |= (uint64_t)bp[(uint64_t)(w + 1) * F2Q_TILE] << 32; hi |= (uint64_t)bp[(uint64_t)(nw + w + 1) * F2Q_TILE] << 32;
+        }
+        return spread16((uint32_t)(lo >> sh) & 0xFFFFu) | (spread16((uint32_t)(hi >> sh) & 0xFFFFu) << 1);
+    }
+    __device__ bool is_n(int pos) const
+    {
+        return qp && ((qp[(uint64_t)planar_qword((uint32_t)pos) * F2Q_TILE] >> (8u * planar_qbyte((uint32_t)pos) + 7u)) & 1u);
+    }
+    __device__ uint8_t byte_of(uint32_t code, int pos) const { return is_n(pos) ? (uint8_t)'N' : (uint8_t)(0x54474341u >> (8u * (code & 3u))); }   // "ACGT"
+    __device__ uint8_t at(int k) const { return byte_of(codes16(start + k), start + k); }
+};
+__device__ __forceinline__ uint64_t key_hash(const PlaneKV &kv)
+{
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)kv.len;
+    for (int k0 = 0; k0 < kv.len; k0 += 16) {
+        uint32_t c = kv.codes16(kv.start + k0);
+        const int n = kv.len - k0 < 16 ? kv.len - k0 : 16;
+        for (int j = 0; j < n; j++, c >>= 2) { h ^= kv.byte_of(c, kv.start + k0 + j); h *= 1099511628211ull; }
+    }
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h;
+}
+__device__ __forceinline__ uint32_t key_word(const PlaneKV &kv, int w)
+{
+    uint32_t c = kv.codes16(kv.start + 4 * w), v = 0;
+    for (int j = 0; j < 4; j++, c >>= 2) if (4 * w + j < kv.len) v |= (uint32_t)kv.byte_of(c, kv.start + 4 * w + j) << (8 * j);
+    return v;
+}
+
+// the reads k_extract_anchor_hot set aside.  Windows the single-word table cannot hold: the key goes to the byte-string
+// table from the planes, at the place the search already found ...
+__global__ __launch_bounds__(256) void k_ec_deferred_keys(EcDev ec, PackedBlock pb, Accum acc, uint64_t read_base,
+                                                          const unsigned long long *__restrict__ defer)
+{
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    unsigned long long n = ec.ctr[F2Q_CTR_ASIDE];
+    if (n > pb.n_slots) n = pb.n_slots;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+        const unsigned long long e = gp(defer)[i];
+        const uint64_t slot = e >> 32;
+        if ((e & F2Q_DEFER_SLOW) || slot >= pb.n_slots) continue;
+        PlaneKV kv;
+        kv.bp = gp(pb.bases) + (slot / F2Q_TILE) * (uint64_t)pb.wb * F2Q_TILE + (slot % F2Q_TILE);
+        kv.qp = (e & F2Q_DEFER_FLAGS) ? gp(pb.qual) + (slot / F2Q_TILE) * (uint64_t)pb.wq * F2Q_TILE + (slot % F2Q_TILE) : nullptr;
+        kv.nw = pb.planar_nw; kv.start = (int)((e >> 16) & 0x3FFFu); kv.len = (int)(e & 0xFFFFu);
+        const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+        ec_insert(ec, kv, gi);
+        st[0]++; st[1]++;
+    }
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
+}
+// ... and the rest (negative-index slices, reads that met a full table): one thread per read, byte-exact routine on
+// the decoded planes
+__global__ __launch_bounds__(256) void k_ec_deferred_slow(const RunDev *__restrict__ runp, const LibDev *__restrict__ libp, EcDev ec,
+                                                          PackedBlock pb, Accum acc, uint64_t read_base,
+                                                          const unsigned long long *__restrict__ defer)
+{
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    unsigned long long n = ec.ctr[F2Q_CTR_ASIDE];
+    if (n > pb.n_slots) n = pb.n_slots;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+        const unsigned long long e = gp(defer)[i];
+        const uint64_t slot = e >> 32;
+        if (!(e & F2Q_DEFER_SLOW) || slot >= pb.n_slots) continue;
+        const uint32_t l = gp(pb.len)[slot];
+        const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+        const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
+        anchor_slow(runp, libp, &ec2, &acc2, &pb2, (uint32_t)(slot / F2Q_TILE), (uint32_t)(slot % F2Q_TILE), (int)(l & 0x7FFFu), gi, st);
+    }
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
+}
+
+// hot-key set of the single-word table: built from the candidates the learning launches noted (in the order they
+// reached F2Q_HOT_MINCOUNT reads, the first F2Q_HOT_CAP of them), re-linked after the table has grown
+__global__ __launch_bounds__(256) void k_ec_hot_build(EcDev ec, EcHot hot)
+{
+    unsigned long long n = ec.ctr[F2Q_CTR_CAND];
+    if (n > F2Q_HOT_CAND) n = F2Q_HOT_CAND;
+    if (n > F2Q_HOT_CAP) n = F2Q_HOT_CAP;
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = hot.cand[i];
+    if (s > ec.k64_mask) return;
+    const unsigned long long k = ec.k64_slots[s];
+    if (k == KEY_EMPTY) return;
+    const HotProbe q = hot_probe(k);
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t b = pass ? q.b2 : q.b1;
+        for (uint32_t j = 0; j < 4u; j++) {
+            // slots of a bucket fill in order and every key scans them in order: a tag is unique within its bucket
+            const uint32_t old = atomicCAS(&hot.tags[4u * b + j], 0u, q.tag);
+            if (old == 0u) {
+                hot.kf[2u * (4u * b + j)] = k; hot.kf[2u * (4u * b + j) + 1u] = ec.k64_first[s];
+                hot.slot[4u * b + j] = s;
+                return;
+            }
+            if (old == q.tag) return;                            // same tag in the bucket: this key stays cold
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_ec_hot_relink(EcDev ec, EcHot hot)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= F2Q_HOT_SLOTS || hot.tags[i] == 0u) return;
+    const unsigned long long k = hot.kf[2u * i];
+    uint32_t s = hash32(k ^ (k >> 29), 32) & ec.k64_mask;
+    for (uint32_t guard = 0; guard <= ec.k64_mask; guard++) {
+        const unsigned long long v = ec.k64_slots[s];
+        if (v == k) { hot.slot[i] = s; return; }
+        if (v == KEY_EMPTY) break;
+        s = (s + 1) & ec.k64_mask;
+    }
+    hot.tags[i] = 0u;                                            // cannot happen (growth keeps every key); stay exact anyway
+}
+
 // Large libraries (no per-workgroup LDS histogram of the whole library): the counting kernel leaves the feature index
 // of every read in hit_buf; here workgroup (range, part) histograms the indices of its part that fall into its range
 // of F2Q_HIST_MAX features in LDS and writes that stretch of slab row `part`.  hit_buf is read n_ranges times, from
@@ -1196,21 +1532,49 @@ struct RawBlock {
     const uint32_t *len, *qlen, *index;    // index: position inside the block (nullptr: == record id)
 };
 
-__global__ __launch_bounds__(256) void k_count_general(const RunDev *__restrict__ runp,
-                                                        const LibDev *__restrict__ libp, EcDev ec, RawBlock rb,
-                                                        Accum acc)
+// One read per lane, byte-exact routine.  The routine walks the record byte by byte with dependent loads, so each lane
+// first copies its record into LDS (aligned 4-byte loads, all in flight together; odd word stride per lane: no bank
+// conflicts) and then works on LDS pointers; a record longer than the staging area is walked in global memory as before.
+// 64-thread workgroups of 24 KiB: they fit beside a workgroup of the hot-key kernel (128 KiB) on the same CU.
+#define F2Q_GEN_THREADS 64
+#define F2Q_GEN_WORDS 48u               // words of a sequence line / of a quality line the staging area holds (192 bytes)
+#define F2Q_GEN_STRIDE 97u              // words per lane: 2 x 48 + 1
+__device__ __forceinline__ void stage_line(uint32_t *dst, gbytes raw, unsigned long long off, int n)
 {
+    // bytes [off, off + n) -> dst, keeping the misalignment: byte i of the line sits at ((uint8_t *)dst)[(off & 3) + i]
+    const uint32_t mis = (uint32_t)off & 3u, full = (mis + (uint32_t)n) >> 2;
+    const uint32_t F2Q_GLOBAL *src = (const uint32_t F2Q_GLOBAL *)(raw + (off - mis));
+#pragma unroll 8
+    for (uint32_t k = 0; k < full; k++) dst[k] = src[k];
+    uint8_t *db = reinterpret_cast<uint8_t *>(dst);
+    for (uint32_t k = 4u * full; k < mis + (uint32_t)n; k++) db[k] = raw[off - mis + k];      // <= 3 bytes, never past the line
+}
+__global__ __launch_bounds__(F2Q_GEN_THREADS) void k_count_general(const RunDev *__restrict__ runp,
+                                                                    const LibDev *__restrict__ libp, EcDev ec, RawBlock rb,
+                                                                    Accum acc)
+{
+    __shared__ uint32_t stage[F2Q_GEN_THREADS * F2Q_GEN_STRIDE];
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
     unsigned long long st[5] = {0, 0, 0, 0, 0};
     uint32_t n_new = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rb.n;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        gbytes seq = gp(rb.raw) + gp(rb.off)[i];
+    const auto raw = gp(rb.raw);
+    uint32_t *mine = stage + threadIdx.x * F2Q_GEN_STRIDE;
+    for (uint64_t i = (uint64_t)blockIdx.x * F2Q_GEN_THREADS + threadIdx.x; i < rb.n; i += (uint64_t)gridDim.x * F2Q_GEN_THREADS) {
+        const unsigned long long so = gp(rb.off)[i];
         const int r = (int)gp(rb.len)[i], qn = (int)gp(rb.qlen)[i];
-        gbytes qual = rb.qoff ? gp(rb.raw) + gp(rb.qoff)[i] : seq + r;
+        const unsigned long long qo = rb.qoff ? gp(rb.qoff)[i] : so + (unsigned long long)r;
         const unsigned long long gi = rb.first_index + (rb.index ? gp(rb.index)[i] : i);
-        general_read(run, lib, ec, acc, seq, r, qual, qn, gi, st, &n_new);
+        const uint32_t ms = (uint32_t)so & 3u, mq = (uint32_t)qo & 3u;
+        if (r >= 0 && qn >= 0 && ms + (uint32_t)r <= 4u * F2Q_GEN_WORDS && mq + (uint32_t)qn <= 4u * F2Q_GEN_WORDS) {
+            stage_line(mine, raw, so, r);
+            stage_line(mine + F2Q_GEN_WORDS, raw, qo, qn);
+            const uint8_t *sl = reinterpret_cast<const uint8_t *>(mine) + ms;
+            const uint8_t *ql = reinterpret_cast<const uint8_t *>(mine + F2Q_GEN_WORDS) + mq;
+            general_read<const uint8_t *>(run, lib, ec, acc, sl, r, ql, qn, gi, st, &n_new);
+        } else {
+            general_read(run, lib, ec, acc, raw + so, r, raw + qo, qn, gi, st, &n_new);
+        }
     }
     if (run.mode == 1) ec64_report_new(ec, n_new);
     __shared__ unsigned long long st_lds[8];

@@ -158,6 +158,82 @@ struct EcDev {
     uint32_t k64_mask, k64_room;       // slots - 1; keys the table may hold before it grows (3/4 of the slots)
 };
 #define F2Q_EC64_MAXLEN 29
+// Single-word form of an Extract+Count key (the text of one window, upper case):
+//   plain ACGT, len <= 29:            (len << 58) | 2-bit codes, base j in bits 2j..2j+1
+//   ACGT with 1..3 'N's, 2*len + 2 + 5*nN <= 58:  ((32 | len) << 58) | codes (an 'N' stored as 0) | nN << 2*len |
+//                                     the positions of the 'N's, ascending, 5 bits each, from bit 2*len + 2
+// Every other key (longer, more 'N's, any other symbol, several parts) lives in the byte-string table; the rule is the
+// same wherever a key is made, so a key never sits in both tables.  ~0 is the empty slot (length field 63: never made).
+#define F2Q_EC64_NFLAG 32u
+#define F2Q_EC64_MAXN 3
+F2Q_HD bool ec64_word(uint64_t codes, uint32_t nmask, int len, unsigned long long &word)
+{
+    if (len < 0 || len > F2Q_EC64_MAXLEN) return false;
+    if (nmask == 0u) { word = ((unsigned long long)len << 58) | codes; return true; }
+    int nn = 0; for (uint32_t m = nmask; m; m &= m - 1u) nn++;
+    if (nn > F2Q_EC64_MAXN || 2 * len + 2 + 5 * nn > 58) return false;
+    unsigned long long w = codes | ((unsigned long long)nn << (2 * len));
+    int sh = 2 * len + 2;
+    for (uint32_t m = nmask; m; m &= m - 1u) {
+        int pos = 0; while (!((m >> pos) & 1u)) pos++;
+        w |= (unsigned long long)pos << sh; sh += 5;
+    }
+    word = ((unsigned long long)(F2Q_EC64_NFLAG | (uint32_t)len) << 58) | w;
+    return true;
+}
+F2Q_HD bool ec64_fits(uint32_t nmask, int len)
+{
+    unsigned long long w;
+    return ec64_word(0ull, nmask, len, w);
+}
+// the key text of a single-word slot -> out (at most 29 bytes); returns its length
+F2Q_HD uint32_t ec64_text(unsigned long long word, char *out)
+{
+    const uint32_t lf = (uint32_t)(word >> 58), len = lf & 31u;
+    for (uint32_t j = 0; j < len; j++) out[j] = "ACGT"[(word >> (2 * j)) & 3];
+    if (lf & F2Q_EC64_NFLAG) {
+        const uint32_t nn = (uint32_t)(word >> (2 * len)) & 3u;
+        for (uint32_t i = 0; i < nn; i++) out[(word >> (2 * len + 2 + 5 * i)) & 31u] = 'N';
+    }
+    return len;
+}
+
+// Extract+Count, hot keys.  Counting a read costs one device-scope atomic on a scattered address (~10 G/s on MI355X), and
+// in a screen most reads carry one of a few thousand keys.  Once the single-word table has seen F2Q_HOT_LEARN reads, the
+// keys seen most often are copied into a small 2-choice bucket table (4 tags per bucket, one ds_read_b128); a workgroup
+// holds the tags and a u32 counter per slot in LDS, counts hits there and adds each counter to the table once, when it
+// ends.  A tag hit is checked against the full key (kf, 16 bytes, L2-resident), so the result is exact; a read that comes
+// before the key's recorded first read takes the ordinary insert, which lowers the minimum.
+#define F2Q_HOT_BUCKETS 4096u
+#define F2Q_HOT_SLOTS (4u * F2Q_HOT_BUCKETS)
+#define F2Q_HOT_CAP 11264u           // keys admitted: load <= 0.69
+#define F2Q_HOT_MINCOUNT 8u          // a key becomes a candidate when the learning reads bring its count to this
+#define F2Q_HOT_CAND 32768u          // candidates noted (in the order they got there: the most frequent first)
+#define F2Q_HOT_NONE 0xFFFFFFFFu
+#define F2Q_HOT_MAXPROBE 96u         // slots an insert looks at before the read is set aside for a grown table
+// words of EcDev.ctr past the four table counters
+#define F2Q_CTR_ASIDE 4              // reads the hot-key kernel set aside in its last launch ...
+#define F2Q_CTR_ASIDE_SLOW 5         // ... of those for the byte-exact routine
+#define F2Q_CTR_CAND 6               // candidates noted so far in this sample
+#define F2Q_CTR_WORDS 8
+struct EcHot {
+    uint32_t *tags;                  // [F2Q_HOT_SLOTS]; 0 = empty
+    unsigned long long *kf;          // [F2Q_HOT_SLOTS][2]: the key's table word, its first read when the set was built
+    uint32_t *slot;                  // [F2Q_HOT_SLOTS]: the key's slot in the single-word table
+    uint32_t *cand;                  // [F2Q_HOT_CAND]: table slots of the candidates
+};
+struct HotProbe { uint32_t b1, b2, tag; };
+F2Q_HD HotProbe hot_probe(unsigned long long k)
+{
+    unsigned long long h = (k ^ (k >> 31)) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    HotProbe q;
+    q.b1 = (uint32_t)h & (F2Q_HOT_BUCKETS - 1u);
+    q.b2 = (uint32_t)(h >> 12) & (F2Q_HOT_BUCKETS - 1u);
+    if (q.b2 == q.b1) q.b2 = q.b1 ^ 1u;
+    q.tag = (uint32_t)(h >> 32) | 1u;
+    return q;
+}
 
 F2Q_HD void acc_add(unsigned long long *p, unsigned long long v)
 {
@@ -625,9 +701,8 @@ F2Q_HD void ec_insert(const EcDev &ec, const KV &kv, unsigned long long read_ind
 // (ctr[3], read by the host between launches only) is NOT bumped here: a counter every new key increments is one
 // address for the whole device, and 0.6 M same-address atomics cost ~9 ms — callers add up their new keys and
 // report them once per wave (ec64_report_new).
-F2Q_HD uint32_t ec64_insert_n(const EcDev &ec, uint64_t key, int len, unsigned long long read_index)
+F2Q_HD uint32_t ec64_insert_word(const EcDev &ec, unsigned long long k, unsigned long long read_index)
 {
-    const unsigned long long k = ((unsigned long long)len << 58) | key;
     uint32_t s = hash32(k ^ (k >> 29), 32) & ec.k64_mask;
     for (uint32_t guard = 0; guard <= ec.k64_mask; guard++) {
         unsigned long long v = F2Q_LD64(&ec.k64_slots[s]);
@@ -646,6 +721,33 @@ F2Q_HD uint32_t ec64_insert_n(const EcDev &ec, uint64_t key, int len, unsigned l
     }
     F2Q_ST64(&ec.ctr[2], 3ull);                          // table full: reported as an error by the host
     return 0;
+}
+F2Q_HD uint32_t ec64_insert_n(const EcDev &ec, uint64_t key, int len, unsigned long long read_index)
+{
+    return ec64_insert_word(ec, ((unsigned long long)len << 58) | key, read_index);
+}
+// the same with a bounded probe sequence: 2 = gave up after max_probe slots, nothing changed (the caller sets the read
+// aside; the host grows the table before such reads are decided)
+F2Q_HD uint32_t ec64_try_insert(const EcDev &ec, unsigned long long k, unsigned long long read_index, uint32_t max_probe,
+                                uint32_t &slot, unsigned long long &count_before)
+{
+    uint32_t s = hash32(k ^ (k >> 29), 32) & ec.k64_mask;
+    for (uint32_t guard = 0; guard < max_probe; guard++) {
+        unsigned long long v = F2Q_LD64(&ec.k64_slots[s]);
+        uint32_t fresh = 0;
+        if (v == KEY_EMPTY) {
+            v = ec_cas(&ec.k64_slots[s], KEY_EMPTY, k);
+            if (v == KEY_EMPTY) { fresh = 1; v = k; }
+        }
+        if (v == k) {
+            count_before = ec_fetch_add(&ec.k64_count[s], 1ull);
+            slot = s;
+            if (read_index < F2Q_LD64(&ec.k64_first[s])) ec_min(&ec.k64_first[s], read_index);
+            return fresh;
+        }
+        s = (s + 1) & ec.k64_mask;
+    }
+    return 2u;
 }
 // one lane at a time (general path, host twin): report immediately
 F2Q_HD void ec64_insert(const EcDev &ec, uint64_t key, int len, unsigned long long read_index)
@@ -696,17 +798,20 @@ F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, 
             if (res == 1 || res == 2) acc_add(&acc.counts[idx], 1ull);
             st[res]++;
         } else {
-            // plain ACGT keys of <= 29 bases go to the single-word table (so that a key never sits in both)
+            // keys that have a single-word form (ec64_word) go to that table, so that a key never sits in both
             bool regular = (kv.nseg == 1 && kv.len <= F2Q_EC64_MAXLEN && ec.k64_slots != nullptr);
-            uint64_t key = 0;
+            uint64_t key = 0; uint32_t nmask = 0;
             for (int j = 0; regular && j < kv.len; j++) {
-                uint32_t c = base_code(up8(kv.seq[kv.a[0] + j]));
-                if (c > 3u) regular = false;
+                const uint8_t ch = up8(kv.seq[kv.a[0] + j]);
+                uint32_t c = base_code(ch);
+                if (c > 3u) { if (ch == (uint8_t)'N') { nmask |= 1u << j; c = 0; } else regular = false; }
                 key |= (uint64_t)(c & 3u) << (2 * j);
             }
+            unsigned long long word = 0;
+            regular = regular && ec64_word(key, nmask, kv.len, word);
             // n_new: the caller sums new single-word keys and reports them once per wave (ec64_report_new)
-            if (regular && n_new) *n_new += ec64_insert_n(ec, key, kv.len, read_index);
-            else if (regular) ec64_insert(ec, key, kv.len, read_index);
+            if (regular && n_new) *n_new += ec64_insert_word(ec, word, read_index);
+            else if (regular) { if (ec64_insert_word(ec, word, read_index)) ec_fetch_add(&ec.ctr[3], 1ull); }
             else ec_insert(ec, kv, read_index);
             st[1]++;                                                             // :387
         }
@@ -1528,6 +1633,7 @@ struct PackPlan {
     int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
     int from = 0;                  // ... and only [from, need) is ever looked at
     bool inband_n = false;         // non-ACGT symbols travel as flag bits (all-ACGT library only)
+    bool n_only = false;           // ... but only the symbol 'N' (Extract+Count: the key spells the symbol, a flag reads 'N')
     bool fast_anchor = false;      // one --us/--ds pair with ACGT anchors: packed bit-plane path
     int kb = 1;                    // counter bits of the anchor search (0: exact, 1: k <= 1, 3: k <= 7)
 };
@@ -1546,7 +1652,7 @@ F2Q_HD bool read_is_clean(const PackPlan &pl, const RecT<P> &r)
         for (uint32_t j = 0; j < r.len; j++) {
             if (r.qual[j] & 0x80) return false;
             const uint8_t c = r.seq[j];
-            if (base_code(c) > 3u && (!pl.inband_n || c == 'a' || c == 'c' || c == 'g' || c == 't')) return false;
+            if (base_code(c) > 3u && (!pl.inband_n || c == 'a' || c == 'c' || c == 'g' || c == 't' || (pl.n_only && c != 'N'))) return false;
         }
         return true;
     }

@@ -362,6 +362,9 @@ inline PackPlan make_plan(const RunDev &run)
     pl.fast_anchor = !run.fixed && run.n_iter == 1 && run.anchors_packed && run.msu >= 0 && run.msd >= 0 &&
                      run.msu <= 7 && run.msd <= 7 && run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN;
     pl.kb = (run.msu == 0 && run.msd == 0) ? 0 : (run.msu <= 1 && run.msd <= 1) ? 1 : 3;
+    // anchored Extract+Count: a read with 'N's keeps to the packed path (an 'N' equals no anchor base; a window that
+    // holds one is spelt out from the planes and the flag bits), any other odd symbol sends the read to the byte-exact path
+    if (run.mode == 1 && pl.fast_anchor) { pl.inband_n = true; pl.n_only = true; }
     return pl;
 }
 

@@ -72,8 +72,21 @@ struct f2q_ctx {
     size_t hit_buf_n = 0;
     // Extract+Count table
     EcDev ec{};
-    std::vector<void *> ec_allocs;
+    std::vector<void *> ec_allocs;       // byte-string side: slots, entry arrays, arena
+    std::vector<void *> ec_allocs64;     // single-word side: k64_*
+    std::vector<void *> ec_allocs_ctr;   // the four counters (outlive the growth of either side)
+    // raw records of an Extract+Count block are decided on a second stream while the packed tiles are counted
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
+    bool aux_busy = false;
     uint64_t ec_slots = 0;
+    // hot keys of the single-word table (EcHot): learnt from the first hot_learn reads of a sample, kept in LDS by
+    // k_extract_anchor_hot; `defer` lists the reads that kernel sets aside for k_ec_deferred
+    EcHot hot{};
+    std::vector<void *> hot_allocs;
+    bool hot_valid = false, no_hot = false;
+    uint64_t hot_learn = (uint64_t)1 << 20, ec_learned = 0;
+    unsigned long long *defer_d = nullptr; size_t defer_cap = 0;
     uint64_t reads_seen = 0;             // global read index of the next block's read 0
     int n_cu = 256;
     bool force_generic = false;           // F2Q_GENERIC=1: run-time window geometry even where a specialisation exists
@@ -88,7 +101,7 @@ struct f2q_ctx {
     size_t dev_idle_bytes = 0, dev_idle_cap = (size_t)8 << 30;
     std::string err;
     // F2Q_TRACE=1: wall-clock split of the host entry points, printed by f2q_count_file (diagnostics only)
-    bool trace = false;
+    bool trace = false, trace_sync = false;
     double tr_frame = 0, tr_count = 0, tr_free = 0, tr_copy = 0, tr_malloc = 0, tr_hipfree = 0, tr_reserve = 0;
     uint64_t n_malloc = 0, n_hipfree = 0, n_reuse = 0, n_rehash = 0;
 };
@@ -270,9 +283,12 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     c->device = p->device;
     { const char *fv = getenv("F2Q_FORCE_V1"); c->force_v1 = fv && fv[0] == '1'; }
     { const char *tr = getenv("F2Q_TRACE"); c->trace = tr && tr[0] == '1'; }
+    { const char *tr = getenv("F2Q_TRACE_SYNC"); c->trace_sync = tr && tr[0] == '1'; }
     { const char *dc = getenv("F2Q_DEV_CACHE_MB"); if (dc && atol(dc) >= 0) c->dev_idle_cap = (size_t)atol(dc) << 20; }
     { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_NO_LT"); c->no_lt = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_NO_HOT"); c->no_hot = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_HOT_LEARN"); if (fv && atol(fv) > 0) c->hot_learn = (uint64_t)atol(fv); }
     { const char *fv = getenv("F2Q_HOST_PACK"); c->host_pack = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_FORCE_GENERAL"); c->force_general = fv && fv[0] == '1'; }
     int rc = setup_run(c);
@@ -311,7 +327,9 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->trace) fprintf(stderr, "[f2q trace] device memory: %llu hipMalloc %.1f ms, %llu hipFree %.1f ms, %llu reused; Extract+Count reserve %.1f ms (%llu rehashes)\n",
                           (unsigned long long)c->n_malloc, c->tr_malloc, (unsigned long long)c->n_hipfree, c->tr_hipfree, (unsigned long long)c->n_reuse, c->tr_reserve, (unsigned long long)c->n_rehash);
-    free_all(c, c->lib_allocs); free_all(c, c->ec_allocs);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    free_all(c, c->lib_allocs); free_all(c, c->ec_allocs); free_all(c, c->ec_allocs64); free_all(c, c->ec_allocs_ctr); free_all(c, c->hot_allocs);
+    if (c->defer_d) (void)hipFree(c->defer_d);
     for (auto &kv : c->dev_idle) (void)hipFree(kv.second);
     c->dev_idle.clear(); c->dev_size.clear();
     if (c->acc_d) (void)hipFree(c->acc_d);
@@ -325,6 +343,9 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
     if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->ev_aux0) (void)hipEventDestroy(c->ev_aux0);
+    if (c->ev_aux1) (void)hipEventDestroy(c->ev_aux1);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -364,7 +385,12 @@ extern "C" int f2q_reset_counts(f2q_ctx *c)
     if (!c) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemsetAsync(c->acc_d, 0, c->acc_n * sizeof(unsigned long long), c->stream));
-    if (c->prm.mode == 1) { free_all(c, c->ec_allocs); memset(&c->ec, 0, sizeof c->ec); c->ec_slots = 0; }
+    if (c->prm.mode == 1) {
+        if (c->aux_stream) HIPC(c, hipStreamSynchronize(c->aux_stream));
+        c->aux_busy = false;
+        free_all(c, c->ec_allocs); free_all(c, c->ec_allocs64); free_all(c, c->ec_allocs_ctr);
+        memset(&c->ec, 0, sizeof c->ec); c->ec_slots = 0; c->hot_valid = false; c->ec_learned = 0;
+    }
     c->reads_seen = 0;
     // no host synchronisation: the clear is ordered on the context's stream like every launch and read-back after it
     return F2Q_OK;
@@ -396,12 +422,28 @@ extern "C" int f2q_counts_device_ptr(f2q_ctx *c, void **dptr, uint64_t *n_int64)
     return F2Q_OK;
 }
 
+// F2Q_TRACE_SYNC=1: name every step of the Extract+Count path on stderr and wait for it (fault localisation only)
+#define EC_POINT(c, what) do { if ((c)->trace_sync) { (void)hipStreamSynchronize((c)->stream); fprintf(stderr, "[f2q sync] %s done\n", what); fflush(stderr); } } while (0)
+
 // ---- Extract+Count table management -----------------------------------------------------------
-static int ec_alloc(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t max_entries, uint64_t arena_words)
+// the two sides of the Extract+Count tables grow independently: the single-word table (k64_*: one slot per plain ACGT
+// key of <= 29 bases) and the byte-string table (slots, entry arrays, arena); the four counters outlive both
+static int ec_alloc64(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t max_keys64)
 {
-    memset(&e, 0, sizeof e);
-    // load factor <= 0.75 even if every read of a launch brings a new key (usually a small fraction of that): smaller
-    // tables are cheaper to clear and stay in the Infinity Cache longer
+    // load factor <= 0.75: smaller tables are cheaper to clear and stay in the Infinity Cache longer
+    uint64_t slots64 = 1024;
+    while (3 * slots64 < 4 * max_keys64) slots64 <<= 1;
+    if (slots64 > (1ull << 32)) return fail(c, F2Q_ENOMEM, "Extract+Count table would exceed 2^32 slots");
+    int rc;
+    if ((rc = dev_alloc(c, slots64, &e.k64_slots, owner, 0xFF))) return rc;
+    if ((rc = dev_alloc(c, slots64, &e.k64_count, owner, 0))) return rc;
+    if ((rc = dev_alloc(c, slots64, &e.k64_first, owner, 0xFF))) return rc;
+    e.k64_mask = (uint32_t)(slots64 - 1);
+    e.k64_room = (uint32_t)std::min<uint64_t>(3 * slots64 / 4, 0xFFFFFFFEull);   // keys the table takes before it must grow
+    return F2Q_OK;
+}
+static int ec_allocB(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t max_entries, uint64_t arena_words)
+{
     uint64_t slots = 1024;
     while (3 * slots < 4 * max_entries) slots <<= 1;
     if (slots > (1ull << 32)) return fail(c, F2Q_ENOMEM, "Extract+Count table would exceed 2^32 slots");
@@ -412,64 +454,88 @@ static int ec_alloc(f2q_ctx *c, EcDev &e, std::vector<void *> &owner, uint64_t m
     if ((rc = dev_alloc(c, max_entries, &e.ent_count, owner, 0))) return rc;
     if ((rc = dev_alloc(c, max_entries, &e.ent_first, owner, 0xFF))) return rc;
     if ((rc = dev_alloc(c, arena_words, &e.arena, owner))) return rc;
-    if ((rc = dev_alloc(c, (size_t)4, &e.ctr, owner, 0))) return rc;
-    if ((rc = dev_alloc(c, slots, &e.k64_slots, owner, 0xFF))) return rc;
-    if ((rc = dev_alloc(c, slots, &e.k64_count, owner, 0))) return rc;
-    if ((rc = dev_alloc(c, slots, &e.k64_first, owner, 0xFF))) return rc;
-    e.k64_mask = (uint32_t)(slots - 1);
     e.mask = (uint32_t)(slots - 1); e.max_entries = (uint32_t)std::min<uint64_t>(max_entries, 0xFFFFFFFEull);
-    e.k64_room = (uint32_t)std::min<uint64_t>(3 * slots / 4, 0xFFFFFFFEull);   // keys the single-word table takes before it must grow
     e.arena_words = arena_words;
     return F2Q_OK;
 }
 
-// make room for `reads` more reads whose keys total at most `key_bytes` bytes
-static int ec_reserve(f2q_ctx *c, uint64_t reads, uint64_t key_bytes)
+// make room for `keys64` more keys in the single-word table and `reads` more entries of at most `key_bytes` bytes in
+// the byte-string table
+// known: the counters as the caller has just read them (nothing has run since), else they are fetched
+static int ec_reserve(f2q_ctx *c, uint64_t keys64, uint64_t reads, uint64_t key_bytes, const unsigned long long *known = nullptr)
 {
     unsigned long long ctr[4] = {0, 0, 0, 0};
-    if (c->ec.slots) {
+    if (known) memcpy(ctr, known, sizeof ctr);
+    else if (c->ec.ctr) {
         HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error)");
+        if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error, code " + std::to_string(ctr[2]) + ")");
     }
-    // both tables have room for "every read of the launch brings a new key" (at most 3/4 of the slots used)
-    const uint64_t need_e = std::max(ctr[0], ctr[3]) + reads + 16, need_w = ctr[1] + (key_bytes + 3) / 4 + reads + 16;
-    // the byte-string table is limited by its entry arrays, the single-word table by its load factor
-    const uint64_t need_b = ctr[0] + reads + 16, need_r = ctr[3] + reads + 16;
-    if (c->ec.slots && need_b <= c->ec.max_entries && need_r <= c->ec.k64_room && need_w <= c->ec.arena_words) return F2Q_OK;
-    // growth doubles the room of the keys already there (amortised rehash), not the head room of one launch
-    uint64_t ne = std::max<uint64_t>(need_e + std::max<uint64_t>(std::max(ctr[0], ctr[3]), reads / 4), 1u << 16);
-    uint64_t nw = std::max<uint64_t>(need_w + std::max<uint64_t>(ctr[1], key_bytes / 16), 1u << 18);
+    // the byte-string table is limited by its entry arrays and its arena, the single-word table by its load factor (<= 3/4)
+    const uint64_t need_b = ctr[0] + reads + 16, need_r = ctr[3] + keys64 + 16, need_w = ctr[1] + (key_bytes + 3) / 4 + reads + 16;
+    const bool grow64 = !c->ec.k64_slots || need_r > c->ec.k64_room;
+    const bool growB = !c->ec.slots || need_b > c->ec.max_entries || need_w > c->ec.arena_words;
+    if (!grow64 && !growB) return F2Q_OK;
     const double rs0 = now_ms();
-    if (c->ec.slots && (ctr[0] || ctr[3])) {
+    // nothing may still be counting into the tables that are about to move
+    if (c->aux_busy) { HIPC(c, hipStreamSynchronize(c->aux_stream)); c->aux_busy = false; }
+    if (c->ec.ctr) {                                             // the exact counters: they say how much is carried over
+        HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error, code " + std::to_string(ctr[2]) + ")");
+    }
+    int rc;
+    if (!c->ec.ctr && (rc = dev_alloc(c, (size_t)F2Q_CTR_WORDS, &c->ec.ctr, c->ec_allocs_ctr, 0))) return rc;
+    if ((c->ec.k64_slots && grow64 && ctr[3]) || (c->ec.slots && growB && ctr[0])) {
         c->n_rehash++;
-        if (c->trace && c->n_rehash <= 4)
-            fprintf(stderr, "[f2q trace] Extract+Count tables grow: keys %llu/%llu, entries needed %llu of %u, arena words needed %llu of %llu\n",
-                    ctr[0], ctr[3], (unsigned long long)need_e, c->ec.max_entries, (unsigned long long)need_w, c->ec.arena_words);
+        if (c->trace && c->n_rehash <= 6)
+            fprintf(stderr, "[f2q trace] Extract+Count tables grow (%s%s): keys %llu/%llu, entries needed %llu of %u, single-word keys needed %llu of %u, arena words needed %llu of %llu\n",
+                    grow64 ? "single-word " : "", growB ? "byte-string" : "", ctr[0], ctr[3], (unsigned long long)need_b, c->ec.max_entries,
+                    (unsigned long long)need_r, c->ec.k64_room, (unsigned long long)need_w, c->ec.arena_words);
     }
-    EcDev fresh; std::vector<void *> owner;
-    int rc = ec_alloc(c, fresh, owner, ne, nw);
-    if (rc) { free_all(c, owner); return rc; }
-    if (c->ec.slots && ctr[0]) {
-        HIPC(c, hipMemcpyAsync(fresh.arena, c->ec.arena, ctr[1] * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(fresh.ent_off, c->ec.ent_off, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(fresh.ent_len, c->ec.ent_len, ctr[0] * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(fresh.ent_count, c->ec.ent_count, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(fresh.ent_first, c->ec.ent_first, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(k_ec_rehash, dim3((unsigned)((ctr[0] + 255) / 256)), dim3(256), 0, c->stream, c->ec, ctr[0], fresh);
-        HIPC(c, hipGetLastError());
+    // growth doubles the room of the keys already there (amortised rehash), not the head room of one launch
+    if (grow64) {
+        const uint64_t nr = std::max<uint64_t>(need_r + std::max<uint64_t>(ctr[3], keys64 / 4), 1u << 16);
+        EcDev fresh = c->ec; std::vector<void *> owner;
+        if ((rc = ec_alloc64(c, fresh, owner, nr))) { free_all(c, owner); return rc; }
+        if (c->ec.k64_slots && ctr[3]) {
+            hipLaunchKernelGGL(k_ec64_rehash, dim3((unsigned)(((uint64_t)c->ec.k64_mask + 256) / 256)), dim3(256), 0, c->stream, c->ec, fresh);
+            HIPC(c, hipGetLastError());
+            EC_POINT(c, "reserve: k_ec64_rehash");
+            if (c->hot_valid) {                                  // the hot keys' slots moved with the table
+                hipLaunchKernelGGL(k_ec_hot_relink, dim3(F2Q_HOT_SLOTS / 256), dim3(256), 0, c->stream, fresh, c->hot);
+                HIPC(c, hipGetLastError());
+                EC_POINT(c, "reserve: k_ec_hot_relink");
+            }
+        }
+        free_all(c, c->ec_allocs64);                             // (waits for the stream)
+        c->ec_allocs64 = owner;
+        c->ec.k64_slots = fresh.k64_slots; c->ec.k64_count = fresh.k64_count; c->ec.k64_first = fresh.k64_first;
+        c->ec.k64_mask = fresh.k64_mask; c->ec.k64_room = fresh.k64_room;
     }
-    if (c->ec.slots) {
-        const unsigned long long carried[4] = {ctr[0], ctr[1], 0ull, ctr[3]};
-        HIPC(c, hipMemcpyAsync(fresh.ctr, carried, sizeof carried, hipMemcpyHostToDevice, c->stream));
+    if (growB) {
+        const uint64_t nb = need_b > c->ec.max_entries || !c->ec.slots ? std::max<uint64_t>(need_b + std::max<uint64_t>(ctr[0], reads / 4), 1u << 12)
+                                                                        : (uint64_t)c->ec.max_entries;
+        const uint64_t nw = need_w > c->ec.arena_words || !c->ec.slots ? std::max<uint64_t>(need_w + std::max<uint64_t>(ctr[1], key_bytes / 16), 1u << 14)
+                                                                       : c->ec.arena_words;
+        EcDev fresh = c->ec; std::vector<void *> owner;
+        if ((rc = ec_allocB(c, fresh, owner, nb, nw))) { free_all(c, owner); return rc; }
+        if (c->ec.slots && ctr[0]) {
+            HIPC(c, hipMemcpyAsync(fresh.arena, c->ec.arena, ctr[1] * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(fresh.ent_off, c->ec.ent_off, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(fresh.ent_len, c->ec.ent_len, ctr[0] * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(fresh.ent_count, c->ec.ent_count, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(fresh.ent_first, c->ec.ent_first, ctr[0] * 8, hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_ec_rehash, dim3((unsigned)((ctr[0] + 255) / 256)), dim3(256), 0, c->stream, c->ec, ctr[0], fresh);
+            HIPC(c, hipGetLastError());
+            EC_POINT(c, "reserve: k_ec_rehash");
+        }
+        free_all(c, c->ec_allocs);
+        c->ec_allocs = owner;
+        c->ec.slots = fresh.slots; c->ec.mask = fresh.mask; c->ec.max_entries = fresh.max_entries;
+        c->ec.ent_off = fresh.ent_off; c->ec.ent_len = fresh.ent_len; c->ec.ent_count = fresh.ent_count; c->ec.ent_first = fresh.ent_first;
+        c->ec.arena = fresh.arena; c->ec.arena_words = fresh.arena_words;
     }
-    if (c->ec.slots && ctr[3]) {
-        hipLaunchKernelGGL(k_ec64_rehash, dim3((unsigned)(((uint64_t)c->ec.k64_mask + 256) / 256)), dim3(256), 0, c->stream, c->ec, fresh);
-        HIPC(c, hipGetLastError());
-    }
-    HIPC(c, hipStreamSynchronize(c->stream));
-    free_all(c, c->ec_allocs);
-    c->ec_allocs = owner; c->ec = fresh;
     c->tr_reserve += now_ms() - rs0;
     return F2Q_OK;
 }
@@ -691,11 +757,117 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
     if (rbv.n) {
         RawBlock rb = rbv;
         rb.first_index += c->reads_seen;
-        const uint64_t wg = (rb.n + 255) / 256;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(wg, (uint64_t)c->n_cu * 16u);
-        hipLaunchKernelGGL(k_count_general, dim3(grid), dim3(256), 0, c->stream, c->run_d, c->lib_d, c->ec, rb, acc);
+        const uint64_t wg = (rb.n + F2Q_GEN_THREADS - 1) / F2Q_GEN_THREADS;
+        uint32_t gmul = 64u; { const char *e = getenv("F2Q_GEN_GRID"); if (e && atoi(e) > 0) gmul = (uint32_t)atoi(e); }
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(wg, (uint64_t)c->n_cu * gmul);
+        hipLaunchKernelGGL(k_count_general, dim3(grid), dim3(F2Q_GEN_THREADS), 0, c->stream, c->run_d, c->lib_d, c->ec, rb, acc);
         HIPC(c, hipGetLastError());
         launches++;
+        EC_POINT(c, "k_count_general");
+    }
+    return F2Q_OK;
+}
+
+// ---- Extract+Count, anchored tiles, hot keys in LDS (EcHot, k_extract_anchor_hot) ---------------------------------
+static int hot_arrays(f2q_ctx *c)
+{
+    if (c->hot.tags) return F2Q_OK;
+    int rc;
+    if ((rc = dev_alloc(c, (size_t)F2Q_HOT_SLOTS, &c->hot.tags, c->hot_allocs, 0))) return rc;
+    if ((rc = dev_alloc(c, (size_t)F2Q_HOT_SLOTS * 2, &c->hot.kf, c->hot_allocs))) return rc;
+    if ((rc = dev_alloc(c, (size_t)F2Q_HOT_SLOTS, &c->hot.slot, c->hot_allocs))) return rc;
+    return dev_alloc(c, (size_t)F2Q_HOT_CAND, &c->hot.cand, c->hot_allocs);
+}
+// the set from the candidates the learning launches noted
+static int hot_build(f2q_ctx *c)
+{
+    int rc = hot_arrays(c);
+    if (rc) return rc;
+    HIPC(c, hipMemsetAsync(c->hot.tags, 0, (size_t)F2Q_HOT_SLOTS * 4, c->stream));
+    if (c->ec.k64_slots) {
+        hipLaunchKernelGGL(k_ec_hot_build, dim3((F2Q_HOT_CAP + 255) / 256), dim3(256), 0, c->stream, c->ec, c->hot);
+        HIPC(c, hipGetLastError());
+        EC_POINT(c, "hot set: build");
+    }
+    c->hot_valid = true;
+    return F2Q_OK;
+}
+
+// one launch of the hot-key kernel over a view of anchored tiles, then the reads it set aside; the tables have room
+// (the caller reserved).  learning: the hot set is not built yet, the kernel runs with an empty one and notes the keys
+// that come up F2Q_HOT_MINCOUNT times.  ctr: the table counters after the launch.
+// the raw records of a block on the second stream (after ev_aux0: tables reserved, block resident)
+static int launch_aux_general(f2q_ctx *c, const f2q_block *b, Accum &acc, uint32_t &launches)
+{
+    HIPC(c, hipStreamWaitEvent(c->aux_stream, c->ev_aux0, 0));
+    RawBlock rb = b->rb;
+    rb.first_index += c->reads_seen;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((rb.n + F2Q_GEN_THREADS - 1) / F2Q_GEN_THREADS, (uint64_t)c->n_cu * 64u);
+    hipLaunchKernelGGL(k_count_general, dim3(grid), dim3(F2Q_GEN_THREADS), 0, c->aux_stream, c->run_d, c->lib_d, c->ec, rb, acc);
+    HIPC(c, hipGetLastError());
+    launches++;
+    c->aux_busy = true;
+    return F2Q_OK;
+}
+
+static int launch_hot(f2q_ctx *c, const PackedBlock &v, Accum &acc, uint32_t &launches, bool learning, unsigned long long ctr[F2Q_CTR_WORDS],
+                      const f2q_block *aux_block)
+{
+    int rc = hot_arrays(c);
+    if (rc) return rc;
+    if (learning) HIPC(c, hipMemsetAsync(c->hot.tags, 0, (size_t)F2Q_HOT_SLOTS * 4, c->stream));   // an empty set
+    if (v.n_slots > c->defer_cap || !c->defer_d) {
+        if (c->defer_d) (void)hipFree(c->defer_d);
+        c->defer_d = nullptr; c->defer_cap = 0;
+        HIPC(c, hipMalloc((void **)&c->defer_d, (size_t)v.n_slots * sizeof(unsigned long long)));
+        c->defer_cap = v.n_slots;
+    }
+    HIPC(c, hipMemsetAsync(c->ec.ctr + F2Q_CTR_ASIDE, 0, 16, c->stream));
+    const int nw = (int)v.planar_nw, kb = c->plan.kb;
+    const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
+    const uint32_t groups = (v.n_tiles + F2Q_ALT_GROUPS - 1) / F2Q_ALT_GROUPS;
+    const uint32_t grid = std::min<uint32_t>(groups, (uint32_t)c->n_cu);
+    const size_t shmem = (size_t)F2Q_HOT_SLOTS * 8;
+#define F2Q_LAUNCH_HOT2(NW_, KB_, SQ_)                                                                                 \
+    do {                                                                                                               \
+        auto kern = k_extract_anchor_hot<NW_, KB_, SQ_>;                                                               \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_ALT_THREADS), shmem, c->stream, c->run_d, c->ec, c->hot, v, acc, \
+                           c->reads_seen, c->defer_d, learning ? 1 : 0);                                               \
+    } while (0)
+#define F2Q_LAUNCH_HOT(NW_, KB_) do { if (sameq) F2Q_LAUNCH_HOT2(NW_, KB_, true); else F2Q_LAUNCH_HOT2(NW_, KB_, false); } while (0)
+    if (nw == 3 && kb == 0) F2Q_LAUNCH_HOT(3, 0);
+    else if (nw == 3 && kb == 1) F2Q_LAUNCH_HOT(3, 1);
+    else if (nw == 3) F2Q_LAUNCH_HOT(3, 3);
+    else if (kb == 0) F2Q_LAUNCH_HOT(5, 0);
+    else if (kb == 1) F2Q_LAUNCH_HOT(5, 1);
+    else F2Q_LAUNCH_HOT(5, 3);
+#undef F2Q_LAUNCH_HOT
+#undef F2Q_LAUNCH_HOT2
+    HIPC(c, hipGetLastError());
+    launches++;
+    if (aux_block && (rc = launch_aux_general(c, aux_block, acc, launches))) return rc;
+    EC_POINT(c, learning ? "k_extract_anchor_hot (learning)" : "k_extract_anchor_hot");
+    HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, F2Q_CTR_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error, code " + std::to_string(ctr[2]) + ")");
+    const unsigned long long n_def = ctr[F2Q_CTR_ASIDE], n_slow = ctr[F2Q_CTR_ASIDE_SLOW];
+    if (n_def) {
+        if ((rc = ec_reserve(c, n_slow, n_def, n_def * ((uint64_t)v.rmax + F2Q_MAX_ITER), ctr))) return rc;
+        const uint32_t g = (uint32_t)std::min<uint64_t>((n_def + 255) / 256, (uint64_t)c->n_cu * 8u);
+        if (n_def > n_slow) {
+            hipLaunchKernelGGL(k_ec_deferred_keys, dim3(g), dim3(256), 0, c->stream, c->ec, v, acc, c->reads_seen, c->defer_d);
+            HIPC(c, hipGetLastError());
+            launches++;
+            EC_POINT(c, "k_ec_deferred_keys");
+        }
+        if (n_slow) {
+            hipLaunchKernelGGL(k_ec_deferred_slow, dim3(g), dim3(256), 0, c->stream, c->run_d, c->lib_d, c->ec, v, acc, c->reads_seen, c->defer_d);
+            HIPC(c, hipGetLastError());
+            launches++;
+            EC_POINT(c, "k_ec_deferred_slow");
+        }
+        ctr[0] += n_def; ctr[1] += (n_def * ((uint64_t)v.rmax + F2Q_MAX_ITER) + 3) / 4 + n_def; ctr[3] += n_slow;   // upper bounds for the caller
     }
     return F2Q_OK;
 }
@@ -723,27 +895,81 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         { const char *e = getenv("F2Q_EC_STEP"); if (e && atol(e) >= F2Q_TILE) step = (uint64_t)atol(e); }
         const uint32_t tiles_per = (uint32_t)std::max<uint64_t>(1, step / F2Q_TILE);
         const RawBlock none{};
-        for (uint32_t t0 = 0; t0 < b->pb.n_tiles; t0 += tiles_per) {
+        auto view_of = [&](uint32_t t0, uint32_t nt) {
             PackedBlock v = b->pb;
-            const uint32_t nt = std::min<uint32_t>(tiles_per, b->pb.n_tiles - t0);
             v.n_tiles = nt; v.n_slots = (uint64_t)nt * F2Q_TILE;
             v.bases += (size_t)t0 * v.wb * F2Q_TILE; v.qual += (size_t)t0 * v.wq * F2Q_TILE;
             if (v.len) v.len += (size_t)t0 * F2Q_TILE;
             if (v.index) v.index += (size_t)t0 * F2Q_TILE; else v.first_index += (uint64_t)t0 * F2Q_TILE;
+            return v;
+        };
+        const bool hot_path = b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot;
+        if (hot_path) {
+            // anchored tiles: hot keys in LDS.  The first hot_learn reads of a sample go through the same kernel with an
+            // empty hot set (every key takes the table's insert); then the set is built and serves the rest of the sample.
+            // The raw records are decided on a second stream while the packed tiles are counted.
+            const uint64_t n = (uint64_t)b->pb.n_tiles * F2Q_TILE;
+            const uint64_t to_learn = c->hot_valid || c->ec_learned >= c->hot_learn ? 0 : std::min<uint64_t>(n, c->hot_learn - c->ec_learned);
+            unsigned long long ctr[F2Q_CTR_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int rc;
+            if (c->ec.ctr) {
+                HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+                HIPC(c, hipStreamSynchronize(c->stream));
+                if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error, code " + std::to_string(ctr[2]) + ")");
+            }
+            // new single-word keys to expect: at the rate the sample has shown once the learning reads are in (a table that
+            // fills up all the same only moves reads to the deferred pass), a guess of one key per six reads before that
+            auto expect_of = [&](uint64_t reads) {
+                const double rate = std::min(1.0, (double)ctr[3] / (double)std::max<uint64_t>(c->ec_learned, 1));
+                return std::min<uint64_t>(reads, (uint64_t)(rate * (double)reads) + 4096);
+            };
+            const uint64_t aside = 4096 + n / 2048;                                 // reads the packed kernel may set aside
+            const uint64_t raw_bytes = b->raw_key_bytes + b->rb.n * F2Q_MAX_ITER + aside * ((uint64_t)b->pb.rmax + F2Q_MAX_ITER);
+            if ((rc = ec_reserve(c, (to_learn ? to_learn + (n - to_learn) / 6 : expect_of(n)) + b->rb.n + aside, b->rb.n + aside, raw_bytes, ctr))) return rc;
+            uint32_t t0 = 0;
+            if (to_learn) {
+                const uint32_t nt = (uint32_t)((to_learn + F2Q_TILE - 1) / F2Q_TILE);
+                if ((rc = launch_hot(c, view_of(0, nt), acc, launches, true, ctr, nullptr))) return rc;
+                c->ec_learned += (uint64_t)nt * F2Q_TILE;
+                t0 = nt;
+                // the sample's own rate replaces the guess
+                if (t0 < b->pb.n_tiles && (rc = ec_reserve(c, expect_of(n - (uint64_t)t0 * F2Q_TILE) + b->rb.n + aside, b->rb.n + aside, raw_bytes, ctr))) return rc;
+            }
+            if (t0 < b->pb.n_tiles && !c->hot_valid && (rc = hot_build(c))) return rc;
+            if (b->rb.n) {
+                if (!c->aux_stream) {
+                    HIPC(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                    HIPC(c, hipEventCreateWithFlags(&c->ev_aux0, hipEventDisableTiming));
+                    HIPC(c, hipEventCreateWithFlags(&c->ev_aux1, hipEventDisableTiming));
+                }
+                HIPC(c, hipEventRecord(c->ev_aux0, c->stream));                     // the tables and the block are ready
+            }
+            // the long launch goes first; the raw records' kernel fills the wave slots it leaves free
+            if (t0 < b->pb.n_tiles) {
+                if ((rc = launch_hot(c, view_of(t0, b->pb.n_tiles - t0), acc, launches, false, ctr, b->rb.n ? b : nullptr))) return rc;
+            } else if (b->rb.n && (rc = launch_aux_general(c, b, acc, launches))) return rc;
+            if (c->aux_busy) {                                                       // join: the block is done when both streams are
+                HIPC(c, hipEventRecord(c->ev_aux1, c->aux_stream));
+                HIPC(c, hipStreamWaitEvent(c->stream, c->ev_aux1, 0));
+                c->aux_busy = false;
+            }
+        } else
+        for (uint32_t t0 = 0; t0 < b->pb.n_tiles; t0 += tiles_per) {
+            const PackedBlock v = view_of(t0, std::min<uint32_t>(tiles_per, b->pb.n_tiles - t0));
             // packed reads give single-window keys of at most rmax bytes
-            int rc = ec_reserve(c, v.n_slots, v.n_slots * ((uint64_t)v.rmax + F2Q_MAX_ITER));
+            int rc = ec_reserve(c, v.n_slots, v.n_slots, v.n_slots * ((uint64_t)v.rmax + F2Q_MAX_ITER));
             if (rc) return rc;
             if ((rc = launch_view(c, v, none, acc, launches))) return rc;
         }
         const PackedBlock nop{};
-        for (uint64_t r0 = 0; r0 < b->rb.n; r0 += step) {
+        for (uint64_t r0 = 0; r0 < b->rb.n && !hot_path; r0 += step) {
             RawBlock v = b->rb;
             v.n = std::min<uint64_t>(step, b->rb.n - r0);
             v.off += r0; v.len += r0; v.qlen += r0;
             if (v.qoff) v.qoff += r0;
             if (v.index) v.index += r0; else v.first_index += r0;
             // no key is longer than its record's bytes + separators (block-wide bound: the arena is never cleared)
-            int rc = ec_reserve(c, v.n, b->raw_key_bytes + v.n * F2Q_MAX_ITER);
+            int rc = ec_reserve(c, v.n, v.n, b->raw_key_bytes + v.n * F2Q_MAX_ITER);
             if (rc) return rc;
             if ((rc = launch_view(c, nop, v, acc, launches))) return rc;
         }
@@ -769,7 +995,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         unsigned long long ctr[4];
         HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
-        if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error)");
+        if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error, code " + std::to_string(ctr[2]) + ")");
     }
     return F2Q_OK;
 }
@@ -1661,7 +1887,7 @@ static int ec_pull(f2q_ctx *c, EcHost &h)
     unsigned long long ctr[4];
     HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error)");
+    if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error, code " + std::to_string(ctr[2]) + ")");
     const uint64_t n = ctr[0];
     if (n) {
         std::vector<uint32_t> len(n), arena(ctr[1] ? ctr[1] : 1);
@@ -1672,6 +1898,9 @@ static int ec_pull(f2q_ctx *c, EcHost &h)
         HIPC(c, hipMemcpy(first.data(), c->ec.ent_first, n * 8, hipMemcpyDeviceToHost));
         if (ctr[1]) HIPC(c, hipMemcpy(arena.data(), c->ec.arena, ctr[1] * 4, hipMemcpyDeviceToHost));
         for (uint64_t e = 0; e < n; e++) {
+            if (off[e] + ((unsigned long long)len[e] + 3) / 4 > ctr[1])
+                return fail(c, F2Q_ESTATE, "Extract+Count entry " + std::to_string(e) + " of " + std::to_string(n) + " is not filled in (offset " +
+                            std::to_string(off[e]) + ", length " + std::to_string(len[e]) + ", arena " + std::to_string(ctr[1]) + " words)");
             h.keys.emplace_back((const char *)(arena.data() + off[e]), len[e]);
             h.cnt.push_back(cnt[e]); h.first.push_back(first[e]);
         }
@@ -1684,10 +1913,9 @@ static int ec_pull(f2q_ctx *c, EcHost &h)
         HIPC(c, hipMemcpy(kf.data(), c->ec.k64_first, ns * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ns; i++) {
             if (ks[i] == KEY_EMPTY) continue;
-            const uint32_t len = (uint32_t)(ks[i] >> 58);
-            std::string k(len, 'A');
-            for (uint32_t j = 0; j < len; j++) k[j] = "ACGT"[(ks[i] >> (2 * j)) & 3];
-            h.keys.push_back(k); h.cnt.push_back(kc[i]); h.first.push_back(kf[i]);
+            char text[32];
+            const uint32_t len = ec64_text(ks[i], text);
+            h.keys.emplace_back(text, len); h.cnt.push_back(kc[i]); h.first.push_back(kf[i]);
         }
     }
     return F2Q_OK;

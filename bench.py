@@ -50,6 +50,7 @@ UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
 B_CONTRACT = 188          # 38 B of 2-bit bases + 150 quality bytes per 150-bp read
 HBM_PEAK_GBS = 8000.0
 SEED = 0xBEEF
+PMC_CHILD_STEPS = 4
 
 
 def parse_args(argv=None):
@@ -131,7 +132,7 @@ def pmc_child(a):
     pkg = importlib.import_module("2fast2q_amd")
     name, _, w = resolve(a, 1)
     c, blk, _, _ = make_job(pkg, w, a, 0, w["n_reads"], 0)
-    for _ in range(4):
+    for _ in range(PMC_CHILD_STEPS):
         c.reset()
         c.count_resident(blk)
     c.read_counts()
@@ -172,14 +173,15 @@ def pmc_traffic(a, dominant):
                     vals.append(float(row["Counter_Value"]))
             if not vals:
                 return None, {"error": f"no {dominant} dispatch in the {counter} pass"}
-            out[counter + "_KiB"] = sum(vals) / len(vals)
+            out[counter + "_KiB"] = sum(vals) / PMC_CHILD_STEPS          # per step: a step may launch the kernel several times
             out["dispatches"] = len(vals)
+            out["steps"] = PMC_CHILD_STEPS
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
         return None, {"error": f"{type(e).__name__}: {e}"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     traffic = (2.0 * out["FETCH_SIZE_KiB"] + out["WRITE_SIZE_KiB"]) * 1024.0
-    out["formula"] = "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, per launch of " + dominant
+    out["formula"] = "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, all launches of " + dominant + " in a step"
     return traffic, out
 
 
@@ -313,7 +315,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     name, scaling, w = resolve(a, world)
-    dominant = "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
+    dominant = "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
 
     traffic, traffic_detail = None, {"error": "skipped"}
     if world == 1 and not a.no_pmc:

@@ -126,13 +126,14 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             const bool ecm = e->run.mode == 1;
             if (aw.ok == 0) { acc.stats[4]++; acc.stats[0]++; }
             else if (aw.ok == 1 && !ecm && (L < 1 || L > F2Q_REG_MAXLEN)) { acc.stats[3]++; acc.stats[0]++; }
-            else if (aw.ok == 1 && ecm && L > F2Q_EC64_MAXLEN) {
+            else if (aw.ok == 1 && ecm && (L > F2Q_EC64_MAXLEN || (flagged && L > 0 && !ec64_fits(plane_extract<NW>(FLG, aw.start, L), L)))) {
                 uint8_t kb[32 * NW];
                 for (int cw = 0; cw < NW; cw++) {
                     const int off = 32 * cw, n = L - off < 32 ? L - off : 32;
                     if (n > 0) {
                         const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
-                        for (int j = 0; j < n; j++) kb[off + j] = (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
+                        const uint32_t fl = plane_extract<NW>(FLG, aw.start + off, n);
+                        for (int j = 0; j < n; j++) kb[off + j] = ((fl >> j) & 1u) ? (uint8_t)'N' : (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
                     }
                 }
                 KeyView kv; kv.seq = kb; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = L; kv.len = L;
@@ -150,7 +151,12 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             } else if (flagged && plane_extract<NW>(FLG, aw.start, L) != 0u) {
                 acc.stats[0]++;
                 const uint32_t forced = plane_extract<NW>(FLG, aw.start, L);
-                if (ecm || e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss) acc.stats[3]++;
+                if (ecm) {
+                    unsigned long long w = 0;
+                    ec64_word(plane_key<NW>(LO, HI, aw.start, L), forced, L, w);
+                    if (ec64_insert_word(e->ec, w, gi)) e->ec.ctr[3]++;
+                    acc.stats[1]++;
+                } else if (e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss) acc.stats[3]++;
                 else {
                     const uint64_t key = plane_key<NW>(LO, HI, aw.start, L);
                     MinTrack tt; tt.init(e->run.miss);
@@ -414,8 +420,7 @@ void emu_ec_get(void *h, uint64_t e_, char *key, uint32_t *len, int64_t *count, 
     if (e_ >= e->ctr[0]) {
         const size_t s = k64_live(e)[e_ - e->ctr[0]];
         const unsigned long long k = e->k64s[s];
-        *len = (uint32_t)(k >> 58); *count = (int64_t)e->k64c[s]; *first = e->k64f[s];
-        for (uint32_t j = 0; j < *len; j++) key[j] = "ACGT"[(k >> (2 * j)) & 3];
+        *len = ec64_text(k, key); *count = (int64_t)e->k64c[s]; *first = e->k64f[s];
         return;
     }
     *len = e->ent_len[e_]; *count = (int64_t)e->ent_count[e_]; *first = e->ent_first[e_];

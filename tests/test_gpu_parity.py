@@ -256,6 +256,7 @@ def test_ec_block_walked_in_steps(P, monkeypatch, step, fixed):
     grown by device rehash in between): tiny steps = many launches and many rehashes inside ONE block, same result,
     same first-seen order"""
     monkeypatch.setenv("F2Q_EC_STEP", step)
+    monkeypatch.setenv("F2Q_NO_HOT", "1")                     # the stepped walk (the hot-key kernel takes whole views)
     guides = synth.make_library(5000, 20, 41)
     if fixed:
         kw = dict(mode="EC", start="10", length=20)
@@ -273,6 +274,82 @@ def test_ec_block_walked_in_steps(P, monkeypatch, step, fixed):
         assert list(stats) == orc.stats()
         assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
         assert t["launches"] >= 60000 // int(step)
+
+
+@pytest.mark.parametrize("learn", ["256", "3000", "20000"])
+@pytest.mark.parametrize("anchors", ["both", "up"])
+def test_ec_hot_keys_vs_oracle(P, monkeypatch, learn, anchors):
+    """anchored Extract+Count with the hot keys in LDS (k_extract_anchor_hot): a screen-like sample (300 guides carry most
+    reads) over three blocks, the set learnt after F2Q_HOT_LEARN reads -- inside the first block, at a block boundary or
+    spanning blocks.  Keys, counts and first-seen order against the oracle, and against the stepped kernel."""
+    monkeypatch.setenv("F2Q_HOT_LEARN", learn)
+    guides = synth.make_library(300, 20, 77)
+    kw = dict(mode="EC", upstream=UP, miss_search_up=1)
+    if anchors == "both":
+        kw["downstream"] = DOWN
+    else:
+        kw["length"] = 20
+    blocks = []
+    with P.Counter(features=guides, miss=1) as gen:
+        for k, n in enumerate((10000, 30000, 50000)):
+            fq = bytes(gen.synth_fastq(seed=300 + k, n_reads=n, read_len=150, cassette=True, up=UP, down=DOWN, p_sub=0.15, p_rand=0.05))
+            blocks.append(sprinkle_symbols(fq, k, rate=0.0003))
+    orc = O.Oracle(**kw)
+    res = []
+    for no_hot in ("0", "1"):
+        monkeypatch.setenv("F2Q_NO_HOT", no_hot)
+        with P.Counter(**kw) as c:
+            for fq in blocks:
+                if no_hot == "0":
+                    orc.count_fastq(fq)
+                _, t = c.count_block(fq, want_timing=True)
+                assert t["fast_reads"] > 0.9 * t["reads"]
+            _, stats = c.read_counts()
+            res.append((list(stats), c.ec_results()))
+    assert res[0][0] == orc.stats() and res[1] == res[0]
+    assert [(k, n) for k, n, _ in res[0][1]] == list(zip(orc.keys(), orc.counts()))
+    assert max(n for _, n, _ in res[0][1]) > 100                  # there were hot keys
+
+
+def test_ec_hot_keys_table_fills_up(P, monkeypatch):
+    """the table is sized for new keys at the rate seen while learning; a later block of all-new keys fills it, the
+    inserts give up after F2Q_HOT_MAXPROBE slots and those reads are decided after the table has grown"""
+    monkeypatch.setenv("F2Q_HOT_LEARN", "4096")
+    guides = synth.make_library(300, 20, 78)
+    kw = dict(mode="EC", upstream=UP, downstream=DOWN)
+    with P.Counter(features=guides, miss=1) as gen:
+        a = bytes(gen.synth_fastq(seed=1, n_reads=8192, read_len=150, cassette=True, up=UP, down=DOWN, p_sub=0.0, p_rand=0.0))
+        b = bytes(gen.synth_fastq(seed=2, n_reads=400000, read_len=150, cassette=True, up=UP, down=DOWN, p_sub=0.0, p_rand=0.95))
+    orc = O.Oracle(**kw)
+    with P.Counter(**kw) as c:
+        launches = 0
+        for fq in (a, b):
+            orc.count_fastq(fq)
+            _, t = c.count_block(fq, want_timing=True)
+            launches += t["launches"]
+        _, stats = c.read_counts()
+        assert list(stats) == orc.stats()
+        assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+    assert launches >= 5                                           # learning, hot launch, deferred passes, raw reads
+
+
+def test_ec_hot_keys_blocks_out_of_order(P, monkeypatch):
+    """a block with LOWER read indices counted after the hot set was built: the snapshot of a hot key's first read sends
+    such reads through the table's insert, which lowers the minimum -> same first-seen order as counting in order"""
+    monkeypatch.setenv("F2Q_HOT_LEARN", "2048")
+    guides = synth.make_library(200, 20, 79)
+    kw = dict(mode="EC", upstream=UP, downstream=DOWN)
+    with P.Counter(features=guides, miss=1) as gen:
+        a = bytes(gen.synth_fastq(seed=11, n_reads=20000, read_len=150, cassette=True, up=UP, down=DOWN, p_sub=0.1))
+        b = bytes(gen.synth_fastq(seed=12, n_reads=30000, read_len=150, cassette=True, up=UP, down=DOWN, p_sub=0.1))
+    orc = O.Oracle(**kw)
+    orc.count_fastq(a); orc.count_fastq(b)
+    with P.Counter(**kw) as c:
+        c.set_read_base(20000); c.count_block(b)
+        c.set_read_base(0); c.count_block(a)
+        _, stats = c.read_counts()
+        assert list(stats) == orc.stats()
+        assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
 
 
 @pytest.mark.parametrize("anchors", ["both", "up", "down"])
@@ -403,6 +480,8 @@ def test_full_size_config5_cross_paths(P, monkeypatch):
     _, sp2, ecp, _ = _full(P, monkeypatch, {}, lib, sl, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
     _, sg2, ecg, _ = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, sl, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
     assert sp2 == sg2 and ecp == ecg
+    _, sn2, ecn, _ = _full(P, monkeypatch, {"F2Q_NO_HOT": "1"}, lib, sl, mode="EC", **{k: v for k, v in kw.items() if k != "miss"})
+    assert sp2 == sn2 and ecp == ecn                              # hot keys in LDS == the stepped kernel
 
 
 def test_full_size_config4_per_gpu(P, monkeypatch):
