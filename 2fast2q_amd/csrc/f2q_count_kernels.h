@@ -1152,12 +1152,20 @@ __device__ __forceinline__ unsigned long long defer_entry(uint64_t slot, bool sl
     return ((unsigned long long)slot << 32) | (slow ? F2Q_DEFER_SLOW : 0ull) | ((unsigned long long)(start & 0x3FFF) << 16) | (unsigned long long)(L & 0xFFFF);
 }
 
+#ifndef F2Q_HOT_THREADS
+#define F2Q_HOT_THREADS 768             // 12 waves per CU (the tables take the CU's LDS: one workgroup each); 1024 threads
+                                        // leave 128 registers per lane and the two tile buffers spill (2.78 vs 2.69 ms)
+#endif
+#define F2Q_HOT_GROUPS (F2Q_HOT_THREADS / F2Q_TILE)
 template <int NW, int KB, bool SAMEQ>
-__global__ __launch_bounds__(F2Q_ALT_THREADS) void k_extract_anchor_hot(const RunDev *__restrict__ runp, EcDev ec, EcHot hot,
+__global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const RunDev *__restrict__ runp, EcDev ec, EcHot hot,
                                                                        PackedBlock pb, Accum acc, uint64_t read_base,
-                                                                       unsigned long long *__restrict__ defer, int learning)
+                                                                       unsigned long long *__restrict__ defer, uint64_t slot_base,
+                                                                       uint64_t defer_cap, int learning)
 {
-    // (defer has room for every slot of the view; an index past it would be a logic error and is reported, not written)
+    // pb: a view of the block's tiles that starts slot_base slots into it; the reads set aside are listed by their slot
+    // in the block.  (defer has room for every slot of the block; an index past it would be a logic error and is
+    // reported, not written)
     unsigned long long *const defer_n = ec.ctr + F2Q_CTR_ASIDE;
     constexpr int NQW = 8 * NW;
     extern __shared__ uint32_t hot_smem[];
@@ -1169,8 +1177,8 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_extract_anchor_hot(const Ru
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(hot.tags);
         v4 *dst = reinterpret_cast<v4 *>(tg);
-        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 4u; i += F2Q_ALT_THREADS) dst[i] = src[i];
-        for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_ALT_THREADS) cnt[i] = 0;
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 4u; i += F2Q_HOT_THREADS) dst[i] = src[i];
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_HOT_THREADS) cnt[i] = 0;
     }
     __syncthreads();
     const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
@@ -1201,7 +1209,7 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_extract_anchor_hot(const Ru
         if (lane == (uint32_t)first) at = ec_fetch_add(defer_n, (unsigned long long)__popcll(m));
         at = __shfl(at, first, 64);
         const unsigned long long di = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (mine && di < pb.n_slots) gpw(defer)[di] = entry;
+        if (mine && di < defer_cap) gpw(defer)[di] = entry;
         else if (mine) F2Q_ST64(&ec.ctr[2], 7ull);
     };
     auto decide_tile = [&](const Planes &p, uint32_t tile) {
@@ -1251,7 +1259,7 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_extract_anchor_hot(const Ru
         const uint64_t slot = (uint64_t)tile * F2Q_TILE + slot_in_tile;
         const unsigned long long lm = __ballot(later);
         if (lm) {
-            set_aside(lm, later, defer_entry(slot, slow, aw.start, L) | (flagged ? F2Q_DEFER_FLAGS : 0ull));
+            set_aside(lm, later, defer_entry(slot_base + slot, slow, aw.start, L) | (flagged ? F2Q_DEFER_FLAGS : 0ull));
             const unsigned long long sm = __ballot(slow);
             if (sm && lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(sm));
         }
@@ -1286,14 +1294,14 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_extract_anchor_hot(const Ru
         }
         const unsigned long long fm = __ballot(full);
         if (fm) {                                               // the table is (nearly) full: decided after it has grown
-            set_aside(fm, full, defer_entry(slot, true, aw.start, L));
+            set_aside(fm, full, defer_entry(slot_base + slot, true, aw.start, L) | (flagged ? F2Q_DEFER_FLAGS : 0ull));
             if (lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(fm));
             w_reads -= (uint32_t)__popcll(fm); w_pass -= (uint32_t)__popcll(fm);
         }
     };
 
-    const uint32_t stride = gridDim.x * F2Q_ALT_GROUPS, last = pb.n_tiles - 1u;
-    uint32_t tile = blockIdx.x * F2Q_ALT_GROUPS + group;
+    const uint32_t stride = gridDim.x * F2Q_HOT_GROUPS, last = pb.n_tiles - 1u;
+    uint32_t tile = blockIdx.x * F2Q_HOT_GROUPS + group;
     {
         Planes pa, pb2;
         if (tile < pb.n_tiles) {
@@ -1316,7 +1324,7 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_extract_anchor_hot(const Ru
     }
     ec64_report_new(ec, n_new);
     __syncthreads();
-    for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_ALT_THREADS) {
+    for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_HOT_THREADS) {
         const uint32_t n = cnt[i];
         if (n) {
             const uint32_t ts = gp(hot.slot)[i];

@@ -85,7 +85,7 @@ struct f2q_ctx {
     EcHot hot{};
     std::vector<void *> hot_allocs;
     bool hot_valid = false, no_hot = false;
-    uint64_t hot_learn = (uint64_t)1 << 20, ec_learned = 0;
+    uint64_t hot_learn = (uint64_t)1 << 19, ec_learned = 0;
     unsigned long long *defer_d = nullptr; size_t defer_cap = 0;
     uint64_t reads_seen = 0;             // global read index of the next block's read 0
     int n_cu = 256;
@@ -793,16 +793,13 @@ static int hot_build(f2q_ctx *c)
     return F2Q_OK;
 }
 
-// one launch of the hot-key kernel over a view of anchored tiles, then the reads it set aside; the tables have room
-// (the caller reserved).  learning: the hot set is not built yet, the kernel runs with an empty one and notes the keys
-// that come up F2Q_HOT_MINCOUNT times.  ctr: the table counters after the launch.
 // the raw records of a block on the second stream (after ev_aux0: tables reserved, block resident)
 static int launch_aux_general(f2q_ctx *c, const f2q_block *b, Accum &acc, uint32_t &launches)
 {
     HIPC(c, hipStreamWaitEvent(c->aux_stream, c->ev_aux0, 0));
     RawBlock rb = b->rb;
     rb.first_index += c->reads_seen;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((rb.n + F2Q_GEN_THREADS - 1) / F2Q_GEN_THREADS, (uint64_t)c->n_cu * 64u);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((rb.n + F2Q_GEN_THREADS - 1) / F2Q_GEN_THREADS, (uint64_t)c->n_cu * 32u);
     hipLaunchKernelGGL(k_count_general, dim3(grid), dim3(F2Q_GEN_THREADS), 0, c->aux_stream, c->run_d, c->lib_d, c->ec, rb, acc);
     HIPC(c, hipGetLastError());
     launches++;
@@ -810,30 +807,26 @@ static int launch_aux_general(f2q_ctx *c, const f2q_block *b, Accum &acc, uint32
     return F2Q_OK;
 }
 
-static int launch_hot(f2q_ctx *c, const PackedBlock &v, Accum &acc, uint32_t &launches, bool learning, unsigned long long ctr[F2Q_CTR_WORDS],
-                      const f2q_block *aux_block)
+// one launch of the hot-key kernel over a view of the block's anchored tiles (it starts slot_base slots into the
+// block); the tables have room (the caller reserved).  learning: the hot set is not built yet, the kernel runs with an
+// empty one and notes the keys that come up F2Q_HOT_MINCOUNT times.  ctr: the counters after the launch.
+static int launch_hot(f2q_ctx *c, const PackedBlock &v, uint64_t slot_base, Accum &acc, uint32_t &launches, bool learning,
+                      unsigned long long ctr[F2Q_CTR_WORDS], const f2q_block *aux_block)
 {
     int rc = hot_arrays(c);
     if (rc) return rc;
     if (learning) HIPC(c, hipMemsetAsync(c->hot.tags, 0, (size_t)F2Q_HOT_SLOTS * 4, c->stream));   // an empty set
-    if (v.n_slots > c->defer_cap || !c->defer_d) {
-        if (c->defer_d) (void)hipFree(c->defer_d);
-        c->defer_d = nullptr; c->defer_cap = 0;
-        HIPC(c, hipMalloc((void **)&c->defer_d, (size_t)v.n_slots * sizeof(unsigned long long)));
-        c->defer_cap = v.n_slots;
-    }
-    HIPC(c, hipMemsetAsync(c->ec.ctr + F2Q_CTR_ASIDE, 0, 16, c->stream));
     const int nw = (int)v.planar_nw, kb = c->plan.kb;
     const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
-    const uint32_t groups = (v.n_tiles + F2Q_ALT_GROUPS - 1) / F2Q_ALT_GROUPS;
+    const uint32_t groups = (v.n_tiles + F2Q_HOT_GROUPS - 1) / F2Q_HOT_GROUPS;
     const uint32_t grid = std::min<uint32_t>(groups, (uint32_t)c->n_cu);
     const size_t shmem = (size_t)F2Q_HOT_SLOTS * 8;
 #define F2Q_LAUNCH_HOT2(NW_, KB_, SQ_)                                                                                 \
     do {                                                                                                               \
         auto kern = k_extract_anchor_hot<NW_, KB_, SQ_>;                                                               \
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_ALT_THREADS), shmem, c->stream, c->run_d, c->ec, c->hot, v, acc, \
-                           c->reads_seen, c->defer_d, learning ? 1 : 0);                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_HOT_THREADS), shmem, c->stream, c->run_d, c->ec, c->hot, v, acc, \
+                           c->reads_seen, c->defer_d, slot_base, (uint64_t)c->defer_cap, learning ? 1 : 0);            \
     } while (0)
 #define F2Q_LAUNCH_HOT(NW_, KB_) do { if (sameq) F2Q_LAUNCH_HOT2(NW_, KB_, true); else F2Q_LAUNCH_HOT2(NW_, KB_, false); } while (0)
     if (nw == 3 && kb == 0) F2Q_LAUNCH_HOT(3, 0);
@@ -851,23 +844,29 @@ static int launch_hot(f2q_ctx *c, const PackedBlock &v, Accum &acc, uint32_t &la
     HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, F2Q_CTR_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (ctr[2]) return fail(c, F2Q_ENOMEM, "Extract+Count table overflow (internal sizing error, code " + std::to_string(ctr[2]) + ")");
+    return F2Q_OK;
+}
+
+// the reads the launches over a block set aside (ctr: the counters as just read): windows the single-word table cannot
+// hold go to the byte-string table from the planes, the rest through the byte-exact routine
+static int hot_aside(f2q_ctx *c, const PackedBlock &blk, Accum &acc, uint32_t &launches, const unsigned long long ctr[F2Q_CTR_WORDS])
+{
     const unsigned long long n_def = ctr[F2Q_CTR_ASIDE], n_slow = ctr[F2Q_CTR_ASIDE_SLOW];
-    if (n_def) {
-        if ((rc = ec_reserve(c, n_slow, n_def, n_def * ((uint64_t)v.rmax + F2Q_MAX_ITER), ctr))) return rc;
-        const uint32_t g = (uint32_t)std::min<uint64_t>((n_def + 255) / 256, (uint64_t)c->n_cu * 8u);
-        if (n_def > n_slow) {
-            hipLaunchKernelGGL(k_ec_deferred_keys, dim3(g), dim3(256), 0, c->stream, c->ec, v, acc, c->reads_seen, c->defer_d);
-            HIPC(c, hipGetLastError());
-            launches++;
-            EC_POINT(c, "k_ec_deferred_keys");
-        }
-        if (n_slow) {
-            hipLaunchKernelGGL(k_ec_deferred_slow, dim3(g), dim3(256), 0, c->stream, c->run_d, c->lib_d, c->ec, v, acc, c->reads_seen, c->defer_d);
-            HIPC(c, hipGetLastError());
-            launches++;
-            EC_POINT(c, "k_ec_deferred_slow");
-        }
-        ctr[0] += n_def; ctr[1] += (n_def * ((uint64_t)v.rmax + F2Q_MAX_ITER) + 3) / 4 + n_def; ctr[3] += n_slow;   // upper bounds for the caller
+    if (!n_def) return F2Q_OK;
+    int rc = ec_reserve(c, n_slow, n_def, n_def * ((uint64_t)blk.rmax + F2Q_MAX_ITER), ctr);
+    if (rc) return rc;
+    const uint32_t g = (uint32_t)std::min<uint64_t>((n_def + 255) / 256, (uint64_t)c->n_cu * 8u);
+    if (n_def > n_slow) {
+        hipLaunchKernelGGL(k_ec_deferred_keys, dim3(g), dim3(256), 0, c->stream, c->ec, blk, acc, c->reads_seen, c->defer_d);
+        HIPC(c, hipGetLastError());
+        launches++;
+        EC_POINT(c, "k_ec_deferred_keys");
+    }
+    if (n_slow) {
+        hipLaunchKernelGGL(k_ec_deferred_slow, dim3(g), dim3(256), 0, c->stream, c->run_d, c->lib_d, c->ec, blk, acc, c->reads_seen, c->defer_d);
+        HIPC(c, hipGetLastError());
+        launches++;
+        EC_POINT(c, "k_ec_deferred_slow");
     }
     return F2Q_OK;
 }
@@ -926,13 +925,21 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             const uint64_t aside = 4096 + n / 2048;                                 // reads the packed kernel may set aside
             const uint64_t raw_bytes = b->raw_key_bytes + b->rb.n * F2Q_MAX_ITER + aside * ((uint64_t)b->pb.rmax + F2Q_MAX_ITER);
             if ((rc = ec_reserve(c, (to_learn ? to_learn + (n - to_learn) / 6 : expect_of(n)) + b->rb.n + aside, b->rb.n + aside, raw_bytes, ctr))) return rc;
+            // the list of reads set aside: room for every slot of the block, cleared once per block
+            if (n > c->defer_cap || !c->defer_d) {
+                if (c->defer_d) (void)hipFree(c->defer_d);
+                c->defer_d = nullptr; c->defer_cap = 0;
+                HIPC(c, hipMalloc((void **)&c->defer_d, (size_t)n * sizeof(unsigned long long)));
+                c->defer_cap = n;
+            }
+            HIPC(c, hipMemsetAsync(c->ec.ctr + F2Q_CTR_ASIDE, 0, 16, c->stream));
             uint32_t t0 = 0;
             if (to_learn) {
                 const uint32_t nt = (uint32_t)((to_learn + F2Q_TILE - 1) / F2Q_TILE);
-                if ((rc = launch_hot(c, view_of(0, nt), acc, launches, true, ctr, nullptr))) return rc;
+                if ((rc = launch_hot(c, view_of(0, nt), 0, acc, launches, true, ctr, nullptr))) return rc;
                 c->ec_learned += (uint64_t)nt * F2Q_TILE;
                 t0 = nt;
-                // the sample's own rate replaces the guess
+                // the sample's own rate replaces the guess (the reads set aside so far are still to come: `aside` covers them)
                 if (t0 < b->pb.n_tiles && (rc = ec_reserve(c, expect_of(n - (uint64_t)t0 * F2Q_TILE) + b->rb.n + aside, b->rb.n + aside, raw_bytes, ctr))) return rc;
             }
             if (t0 < b->pb.n_tiles && !c->hot_valid && (rc = hot_build(c))) return rc;
@@ -946,8 +953,9 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             }
             // the long launch goes first; the raw records' kernel fills the wave slots it leaves free
             if (t0 < b->pb.n_tiles) {
-                if ((rc = launch_hot(c, view_of(t0, b->pb.n_tiles - t0), acc, launches, false, ctr, b->rb.n ? b : nullptr))) return rc;
+                if ((rc = launch_hot(c, view_of(t0, b->pb.n_tiles - t0), (uint64_t)t0 * F2Q_TILE, acc, launches, false, ctr, b->rb.n ? b : nullptr))) return rc;
             } else if (b->rb.n && (rc = launch_aux_general(c, b, acc, launches))) return rc;
+            if ((rc = hot_aside(c, view_of(0, b->pb.n_tiles), acc, launches, ctr))) return rc;
             if (c->aux_busy) {                                                       // join: the block is done when both streams are
                 HIPC(c, hipEventRecord(c->ev_aux1, c->aux_stream));
                 HIPC(c, hipStreamWaitEvent(c->stream, c->ev_aux1, 0));
