@@ -175,7 +175,8 @@ struct IngestDev {
     uint32_t *meta;                              // [0] longest packed length among clean reads
 };
 
-__device__ __forceinline__ uint32_t rstrip_dev(gbytes p, uint32_t n)
+template <class P>
+__device__ __forceinline__ uint32_t rstrip_dev(P p, uint32_t n)
 {
     while (n > 0) {
         const uint8_t c = p[n - 1];
@@ -184,19 +185,62 @@ __device__ __forceinline__ uint32_t rstrip_dev(gbytes p, uint32_t n)
     return n;
 }
 
-__global__ __launch_bounds__(256) void k_classify(IngestDev d, PackPlan pl)
+// The records of a wave are neighbours in the text, so the wave first copies the stretch that holds all 64 of them
+// into LDS with 16-byte loads (every byte of the text is fetched once, coalesced) and the lanes then walk their
+// records there.  One thread per record walking global memory byte by byte re-fetched every 128-byte line dozens of
+// times (r02 PMC: 47x and 68x the text for k_classify / k_pack).  A stretch longer than the staging area (reads of
+// several hundred bases) is walked in global memory as before.
+#define F2Q_ING_THREADS 64
+#define F2Q_ING_LDS (40u * 1024u)
+// text[lo, hi) -> lds; byte x of the text is then at lds[x - (lo & ~15)]
+__device__ __forceinline__ void stage_span(uint8_t *lds, gbytes text, uint32_t lo, uint32_t hi)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= d.n_records) return;
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint32_t lane = threadIdx.x & 63u, a0 = lo & ~15u, a1 = hi & ~15u;
+    const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)(text + a0);
+    v4 *dst = reinterpret_cast<v4 *>(lds);
+    const uint32_t ng = a1 > a0 ? (a1 - a0) >> 4 : 0u;
+    for (uint32_t g = lane; g < ng; g += 64u) dst[g] = src[g];
+    for (uint32_t x = (a1 > a0 ? a1 : a0) + lane; x < hi; x += 64u) lds[x - a0] = text[x];   // the last < 16 bytes, never past hi
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+__global__ __launch_bounds__(F2Q_ING_THREADS) void k_classify(IngestDev d, PackPlan pl)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[F2Q_ING_LDS];
+    const uint32_t r0 = blockIdx.x * F2Q_ING_THREADS, r = r0 + threadIdx.x;
+    const uint32_t n_act = d.n_records - r0 < F2Q_ING_THREADS ? d.n_records - r0 : F2Q_ING_THREADS;
+    const bool live = r < d.n_records;
     const auto ls = gp(d.line_start);
-    const uint32_t s0 = ls[4u * r + 1u], e0 = ls[4u * r + 2u] - 1u, s1 = ls[4u * r + 3u], e1 = ls[4u * r + 4u] - 1u;
-    RecT<gbytes> rec;
-    rec.seq = gp(d.text) + s0; rec.qual = gp(d.text) + s1;
-    rec.len = rstrip_dev(rec.seq, e0 - s0); rec.qlen = rstrip_dev(rec.qual, e1 - s1);
-    gpw(d.r_off)[r] = s0; gpw(d.r_len)[r] = rec.len; gpw(d.r_qoff)[r] = s1; gpw(d.r_qlen)[r] = rec.qlen;
-    const bool clean = read_is_clean(pl, rec);
-    gpw(d.clean)[r] = clean ? 1u : 0u;
-    if (clean) atomicMax(&d.meta[0], packed_len(pl, rec));
+    const uint32_t rr = live ? r : d.n_records - 1u;
+    const uint32_t s0 = ls[4u * rr + 1u], e0 = ls[4u * rr + 2u] - 1u, s1 = ls[4u * rr + 3u], e1 = ls[4u * rr + 4u] - 1u;
+    const uint32_t lo = __shfl(s0, 0, 64), hi = __shfl(e1, (int)n_act - 1, 64);
+    const bool fits = hi >= lo && hi - (lo & ~15u) <= F2Q_ING_LDS;
+    bool clean = false; uint32_t len = 0, qlen = 0, plen = 0;
+    if (fits) {
+        stage_span(stage, gp(d.text), lo, hi);
+        if (live) {
+            const uint32_t a0 = lo & ~15u;
+            RecT<const uint8_t *> rec;
+            rec.seq = stage + (s0 - a0); rec.qual = stage + (s1 - a0);
+            rec.len = rstrip_dev(rec.seq, e0 - s0); rec.qlen = rstrip_dev(rec.qual, e1 - s1);
+            clean = read_is_clean(pl, rec); len = rec.len; qlen = rec.qlen; plen = packed_len(pl, rec);
+        }
+    } else if (live) {
+        RecT<gbytes> rec;
+        rec.seq = gp(d.text) + s0; rec.qual = gp(d.text) + s1;
+        rec.len = rstrip_dev(rec.seq, e0 - s0); rec.qlen = rstrip_dev(rec.qual, e1 - s1);
+        clean = read_is_clean(pl, rec); len = rec.len; qlen = rec.qlen; plen = packed_len(pl, rec);
+    }
+    if (live) {
+        gpw(d.r_off)[r] = s0; gpw(d.r_len)[r] = len; gpw(d.r_qoff)[r] = s1; gpw(d.r_qlen)[r] = qlen;
+        gpw(d.clean)[r] = clean ? 1u : 0u;
+    }
+    // the longest packed read: one atomic per wave
+    uint32_t m = (live && clean) ? plen : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(m, off, 64); m = o > m ? o : m; }
+    if (threadIdx.x == 0 && m) atomicMax(&d.meta[0], m);
 }
 
 struct DevSink {
@@ -212,24 +256,44 @@ struct PackOut {
 };
 
 // clean_before = exclusive prefix sum of IngestDev::clean
-__global__ __launch_bounds__(256) void k_pack(IngestDev d, PackPlan pl, const uint32_t *clean_before, PackOut o)
+__global__ __launch_bounds__(F2Q_ING_THREADS) void k_pack(IngestDev d, PackPlan pl, const uint32_t *clean_before, PackOut o)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= d.n_records) return;
-    const uint32_t slot = gp(clean_before)[r];
-    RecT<gbytes> rec;
-    rec.seq = gp(d.text) + gp(d.r_off)[r]; rec.qual = gp(d.text) + gp(d.r_qoff)[r];
-    rec.len = gp(d.r_len)[r]; rec.qlen = gp(d.r_qlen)[r];
-    if (gp(d.clean)[r]) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[F2Q_ING_LDS];
+    const uint32_t r0 = blockIdx.x * F2Q_ING_THREADS, r = r0 + threadIdx.x;
+    const uint32_t n_act = d.n_records - r0 < F2Q_ING_THREADS ? d.n_records - r0 : F2Q_ING_THREADS;
+    const bool live = r < d.n_records;
+    const uint32_t rr = live ? r : d.n_records - 1u;
+    const uint32_t off = gp(d.r_off)[rr], qoff = gp(d.r_qoff)[rr], len = gp(d.r_len)[rr], qlen = gp(d.r_qlen)[rr];
+    const bool clean = live && gp(d.clean)[rr] != 0u;
+    const uint32_t slot = gp(clean_before)[rr];
+    // the stretch of text the wave's clean records lie in (none clean: nothing to read)
+    const unsigned long long cm = __ballot(clean);
+    bool fits = false; uint32_t lo = 0;
+    if (cm) {
+        lo = __shfl(off, __builtin_ctzll(cm), 64);
+        const uint32_t hi = __shfl(qoff + qlen, 63 - __builtin_clzll(cm), 64);
+        (void)n_act;
+        fits = hi >= lo && hi - (lo & ~15u) <= F2Q_ING_LDS;
+        if (fits) stage_span(stage, gp(d.text), lo, hi);
+    }
+    if (!live) return;
+    if (clean) {
         const uint64_t tile = slot / F2Q_TILE, lane = slot % F2Q_TILE;
         DevSink sink{gpw(o.bases) + tile * o.wb * F2Q_TILE + lane, gpw(o.qual) + tile * o.wq * F2Q_TILE + lane,
                      gpw(o.len) + tile * F2Q_TILE + lane};
-        pack_read(pl, rec, o.planar_nw, sink);
+        if (fits) {
+            const uint32_t a0 = lo & ~15u;
+            RecT<const uint8_t *> rec; rec.seq = stage + (off - a0); rec.qual = stage + (qoff - a0); rec.len = len; rec.qlen = qlen;
+            pack_read(pl, rec, o.planar_nw, sink);
+        } else {
+            RecT<gbytes> rec; rec.seq = gp(d.text) + off; rec.qual = gp(d.text) + qoff; rec.len = len; rec.qlen = qlen;
+            pack_read(pl, rec, o.planar_nw, sink);
+        }
         if (o.c_index) gpw(o.c_index)[slot] = r;
     } else {
         const uint32_t g = r - slot;
-        gpw(o.g_off)[g] = gp(d.r_off)[r]; gpw(o.g_qoff)[g] = gp(d.r_qoff)[r];
-        gpw(o.g_len)[g] = rec.len; gpw(o.g_qlen)[g] = rec.qlen; gpw(o.g_index)[g] = r;
+        gpw(o.g_off)[g] = off; gpw(o.g_qoff)[g] = qoff;
+        gpw(o.g_len)[g] = len; gpw(o.g_qlen)[g] = qlen; gpw(o.g_index)[g] = r;
     }
 }
 

@@ -1157,11 +1157,11 @@ __device__ __forceinline__ unsigned long long defer_entry(uint64_t slot, bool sl
                                         // leave 128 registers per lane and the two tile buffers spill (2.78 vs 2.69 ms)
 #endif
 #define F2Q_HOT_GROUPS (F2Q_HOT_THREADS / F2Q_TILE)
-template <int NW, int KB, bool SAMEQ>
+template <int NW, int KB, bool SAMEQ, bool LEARN>
 __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const RunDev *__restrict__ runp, EcDev ec, EcHot hot,
                                                                        PackedBlock pb, Accum acc, uint64_t read_base,
                                                                        unsigned long long *__restrict__ defer, uint64_t slot_base,
-                                                                       uint64_t defer_cap, int learning)
+                                                                       uint64_t defer_cap)
 {
     // pb: a view of the block's tiles that starts slot_base slots into it; the reads set aside are listed by their slot
     // in the block.  (defer has room for every slot of the block; an index past it would be a logic error and is
@@ -1284,10 +1284,10 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
         if (hit) atomicAdd(&cnt[s], 1u);
         else if (ins) {
             uint32_t ts = 0; unsigned long long before = 0;
-            const uint32_t rr = ec64_try_insert(ec, k, gi, F2Q_HOT_MAXPROBE, ts, before);
+            const uint32_t rr = ec64_try_insert<LEARN>(ec, k, gi, F2Q_HOT_MAXPROBE, ts, before);
             full = rr == 2u;
             n_new += rr & 1u;
-            if (learning && rr != 2u && before + 1ull == F2Q_HOT_MINCOUNT) {       // a few thousand times per sample
+            if (LEARN && rr != 2u && before + 1ull == F2Q_HOT_MINCOUNT) {       // a few thousand times per sample
                 const unsigned long long at = ec_fetch_add(ec.ctr + F2Q_CTR_CAND, 1ull);
                 if (at < F2Q_HOT_CAND) gpw(hot.cand)[at] = ts;
             }
@@ -1341,18 +1341,30 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
 // key bytes read straight from the bit planes of a tile slot, 32 bases per pair of loads (ec_insert needs len,
 // key_hash() and key_word())
 struct PlaneKV {
-    const uint32_t F2Q_GLOBAL *bp;          // the slot's column of the tile's base planes
-    const uint32_t F2Q_GLOBAL *qp;          // ... of its quality planes (flag bits), or nullptr: the read has no flagged base
+    uint32_t lo[5], hi[5];                  // the slot's base planes (loaded together, once)
+    const uint32_t F2Q_GLOBAL *qp;          // the slot's column of the quality planes (flag bits), or nullptr: no flagged base
     uint32_t nw;
     int start, len;
+    __device__ void load(const uint32_t F2Q_GLOBAL *bp, uint32_t nw_)
+    {
+        nw = nw_;
+#pragma unroll
+        for (uint32_t w = 0; w < 5u; w++) {
+            const uint32_t ww = w < nw_ ? w : nw_ - 1u;
+            lo[w] = bp[(uint64_t)ww * F2Q_TILE]; hi[w] = bp[(uint64_t)(nw_ + ww) * F2Q_TILE];
+        }
+    }
     __device__ uint32_t codes16(int from) const      // 16 bases from position `from` as 2-bit codes (LSB first)
     {
-        const int w = from >> 5, sh = from & 31;
-        uint64_t lo = bp[(uint64_t)w * F2Q_TILE], hi = bp[(uint64_t)(nw + w) * F2Q_TILE];
-        if (sh > 16 && (uint32_t)(w + 1) < nw) {
-            lo |= (uint64_t)bp[(uint64_t)(w + 1) * F2Q_TILE] << 32; hi |= (uint64_t)bp[(uint64_t)(nw + w + 1) * F2Q_TILE] << 32;
+        const uint32_t w = (uint32_t)from >> 5, sh = (uint32_t)from & 31u;
+        uint32_t l0 = 0, h0 = 0, l1 = 0, h1 = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 5u; i++) {               // register arrays: select, never index
+            if (i == w) { l0 = lo[i]; h0 = hi[i]; }
+            if (i == w + 1u) { l1 = lo[i]; h1 = hi[i]; }
         }
-        return spread16((uint32_t)(lo >> sh) & 0xFFFFu) | (spread16((uint32_t)(hi >> sh) & 0xFFFFu) << 1);
+        const uint64_t l = (uint64_t)l0 | ((uint64_t)l1 << 32), h = (uint64_t)h0 | ((uint64_t)h1 << 32);
+        return spread16((uint32_t)(l >> sh) & 0xFFFFu) | (spread16((uint32_t)(h >> sh) & 0xFFFFu) << 1);
     }
     __device__ bool is_n(int pos) const
     {
@@ -1392,9 +1404,9 @@ __global__ __launch_bounds__(256) void k_ec_deferred_keys(EcDev ec, PackedBlock 
         const uint64_t slot = e >> 32;
         if ((e & F2Q_DEFER_SLOW) || slot >= pb.n_slots) continue;
         PlaneKV kv;
-        kv.bp = gp(pb.bases) + (slot / F2Q_TILE) * (uint64_t)pb.wb * F2Q_TILE + (slot % F2Q_TILE);
+        kv.load(gp(pb.bases) + (slot / F2Q_TILE) * (uint64_t)pb.wb * F2Q_TILE + (slot % F2Q_TILE), pb.planar_nw);
         kv.qp = (e & F2Q_DEFER_FLAGS) ? gp(pb.qual) + (slot / F2Q_TILE) * (uint64_t)pb.wq * F2Q_TILE + (slot % F2Q_TILE) : nullptr;
-        kv.nw = pb.planar_nw; kv.start = (int)((e >> 16) & 0x3FFFu); kv.len = (int)(e & 0xFFFFu);
+        kv.start = (int)((e >> 16) & 0x3FFFu); kv.len = (int)(e & 0xFFFFu);
         const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
         ec_insert(ec, kv, gi);
         st[0]++; st[1]++;

@@ -614,6 +614,14 @@ F2Q_HD unsigned long long ec_cas(unsigned long long *p, unsigned long long cmp, 
     unsigned long long old = *p; if (old == cmp) *p = val; return old;
 #endif
 }
+F2Q_HD void ec_add(unsigned long long *p, unsigned long long v)           // result unused: the compiler emits the no-return form
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)__hip_atomic_fetch_add(gpw(p), v, __ATOMIC_RELAXED, F2Q_EC_SCOPE);
+#else
+    *p += v;
+#endif
+}
 F2Q_HD unsigned long long ec_fetch_add(unsigned long long *p, unsigned long long v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -727,22 +735,28 @@ F2Q_HD uint32_t ec64_insert_n(const EcDev &ec, uint64_t key, int len, unsigned l
     return ec64_insert_word(ec, ((unsigned long long)len << 58) | key, read_index);
 }
 // the same with a bounded probe sequence: 2 = gave up after max_probe slots, nothing changed (the caller sets the read
-// aside; the host grows the table before such reads are decided)
+// aside; the host grows the table before such reads are decided).  The key word and the first-read word of a slot are
+// fetched together (one wait instead of two; a stale first-read word is only ever too high, which costs a spare
+// atomic-min at worst).  WANT_COUNT: the count before this read comes back (learning launches note candidates by it);
+// without it the increment is a fire-and-forget atomic.
+template <bool WANT_COUNT>
 F2Q_HD uint32_t ec64_try_insert(const EcDev &ec, unsigned long long k, unsigned long long read_index, uint32_t max_probe,
                                 uint32_t &slot, unsigned long long &count_before)
 {
     uint32_t s = hash32(k ^ (k >> 29), 32) & ec.k64_mask;
     for (uint32_t guard = 0; guard < max_probe; guard++) {
         unsigned long long v = F2Q_LD64(&ec.k64_slots[s]);
+        unsigned long long f = F2Q_LD64(&ec.k64_first[s]);
         uint32_t fresh = 0;
         if (v == KEY_EMPTY) {
             v = ec_cas(&ec.k64_slots[s], KEY_EMPTY, k);
             if (v == KEY_EMPTY) { fresh = 1; v = k; }
         }
         if (v == k) {
-            count_before = ec_fetch_add(&ec.k64_count[s], 1ull);
+            if (WANT_COUNT) count_before = ec_fetch_add(&ec.k64_count[s], 1ull);
+            else ec_add(&ec.k64_count[s], 1ull);
             slot = s;
-            if (read_index < F2Q_LD64(&ec.k64_first[s])) ec_min(&ec.k64_first[s], read_index);
+            if (read_index < f) ec_min(&ec.k64_first[s], read_index);
             return fresh;
         }
         s = (s + 1) & ec.k64_mask;

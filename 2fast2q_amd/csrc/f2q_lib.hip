@@ -823,10 +823,10 @@ static int launch_hot(f2q_ctx *c, const PackedBlock &v, uint64_t slot_base, Accu
     const size_t shmem = (size_t)F2Q_HOT_SLOTS * 8;
 #define F2Q_LAUNCH_HOT2(NW_, KB_, SQ_)                                                                                 \
     do {                                                                                                               \
-        auto kern = k_extract_anchor_hot<NW_, KB_, SQ_>;                                                               \
+        auto kern = learning ? k_extract_anchor_hot<NW_, KB_, SQ_, true> : k_extract_anchor_hot<NW_, KB_, SQ_, false>; \
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_HOT_THREADS), shmem, c->stream, c->run_d, c->ec, c->hot, v, acc, \
-                           c->reads_seen, c->defer_d, slot_base, (uint64_t)c->defer_cap, learning ? 1 : 0);            \
+                           c->reads_seen, c->defer_d, slot_base, (uint64_t)c->defer_cap);                              \
     } while (0)
 #define F2Q_LAUNCH_HOT(NW_, KB_) do { if (sameq) F2Q_LAUNCH_HOT2(NW_, KB_, true); else F2Q_LAUNCH_HOT2(NW_, KB_, false); } while (0)
     if (nw == 3 && kb == 0) F2Q_LAUNCH_HOT(3, 0);
@@ -1146,8 +1146,8 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     if ((rc = dev_alloc(c, (size_t)n_rec + 1, &ing.clean, tmp, 0))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)n_rec + 1, &d_before, tmp))) return bail(rc);
     if ((rc = dev_alloc(c, (size_t)4, &ing.meta, tmp, 0))) return bail(rc);
-    const unsigned rgrid = (n_rec + 255u) / 256u;
-    hipLaunchKernelGGL(k_classify, dim3(rgrid), dim3(256), 0, c->stream, ing, c->plan);
+    const unsigned igrid = (unsigned)((n_rec + F2Q_ING_THREADS - 1u) / F2Q_ING_THREADS);
+    hipLaunchKernelGGL(k_classify, dim3(igrid), dim3(F2Q_ING_THREADS), 0, c->stream, ing, c->plan);
     ING(hipGetLastError());
     size_t cub2 = 0;
     ING(hipcub::DeviceScan::ExclusiveSum(nullptr, cub2, ing.clean, d_before, (int)n_rec + 1, c->stream));
@@ -1186,7 +1186,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
         b->raw_key_bytes = nbytes;                    // the records point into the text: no key is longer than its record
     }
     b->n_general = n_dirty;
-    hipLaunchKernelGGL(k_pack, dim3(rgrid), dim3(256), 0, c->stream, ing, c->plan, d_before, o);
+    hipLaunchKernelGGL(k_pack, dim3(igrid), dim3(F2Q_ING_THREADS), 0, c->stream, ing, c->plan, d_before, o);
     ING(hipGetLastError());
     ING(hipStreamSynchronize(c->stream));             // scratch dies with this frame
 #undef ING
