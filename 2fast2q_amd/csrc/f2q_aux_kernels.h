@@ -122,6 +122,63 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
     }
 }
 
+// ---- exclusive prefix sum of u32 (the two sums of the ingest: newlines per chunk, clean reads per record) -------------
+// Three small launches: every workgroup scans its block of F2Q_SCAN_BLOCK values in LDS and leaves the block total,
+// one workgroup scans the totals, the third launch adds them back.  n is a few million at most (one value per 4 KiB of
+// text or per record), so this is microseconds; out[i] = in[0] + ... + in[i-1].
+#define F2Q_SCAN_THREADS 256
+#define F2Q_SCAN_ITEMS 8
+#define F2Q_SCAN_BLOCK (F2Q_SCAN_THREADS * F2Q_SCAN_ITEMS)
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds /* [F2Q_SCAN_THREADS / 64 + 1] */, uint32_t &total)
+{
+    // inclusive scan inside the wave by shuffles, wave totals through LDS
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= (uint32_t)off) x += y; }
+    if (lane == 63u) lds[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < F2Q_SCAN_THREADS / 64; w++) { const uint32_t t = lds[w]; if (w < wave) before += t; tot += t; }
+    __syncthreads();
+    total = tot;
+    return before + x - v;
+}
+__global__ __launch_bounds__(F2Q_SCAN_THREADS) void k_scan_blocks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
+                                                                  uint32_t *__restrict__ block_sums)
+{
+    __shared__ uint32_t lds[F2Q_SCAN_THREADS / 64 + 1];
+    const uint32_t base = blockIdx.x * F2Q_SCAN_BLOCK + threadIdx.x * F2Q_SCAN_ITEMS;
+    uint32_t v[F2Q_SCAN_ITEMS], mine = 0;
+#pragma unroll
+    for (int i = 0; i < F2Q_SCAN_ITEMS; i++) { v[i] = base + i < n ? in[base + i] : 0u; mine += v[i]; }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(mine, lds, total);
+#pragma unroll
+    for (int i = 0; i < F2Q_SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(F2Q_SCAN_THREADS) void k_scan_sums(uint32_t *__restrict__ block_sums, uint32_t n_blocks)
+{
+    __shared__ uint32_t lds[F2Q_SCAN_THREADS / 64 + 1];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += F2Q_SCAN_THREADS) {
+        const uint32_t i = b0 + threadIdx.x, v = i < n_blocks ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, lds, total);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+}
+__global__ __launch_bounds__(F2Q_SCAN_THREADS) void k_scan_add(uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ block_sums)
+{
+    const uint32_t add = block_sums[blockIdx.x];
+    const uint32_t base = blockIdx.x * F2Q_SCAN_BLOCK + threadIdx.x * F2Q_SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < F2Q_SCAN_ITEMS; i++) if (base + i < n) out[base + i] += add;
+}
+
 // ---- device-side ingest: FASTQ text -> record table -> tiles ------------------------------------------
 // The host only moves the text to the device.  k_nl_count / k_line_starts find every line start (two passes
 // around a device-wide prefix sum), k_classify applies fastq_parser's framing (4 rstrip()-ed lines per record,
@@ -145,11 +202,11 @@ __device__ __forceinline__ uint32_t nl_mask16(const uint8_t F2Q_GLOBAL *text, ui
 
 __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *text, uint64_t nbytes, uint32_t *chunk_counts)
 {
-    typedef hipcub::BlockReduce<uint32_t, 256> BR;
-    __shared__ typename BR::TempStorage tmp;
+    __shared__ uint32_t lds[F2Q_SCAN_THREADS / 64 + 1];
     const uint64_t pos = (uint64_t)blockIdx.x * F2Q_NL_CHUNK + threadIdx.x * 16u;
     const uint32_t c = __popc(nl_mask16(gp(text), pos, nbytes));
-    const uint32_t tot = BR(tmp).Sum(c);
+    uint32_t tot;
+    (void)block_exclusive_scan(c, lds, tot);
     if (threadIdx.x == 0) chunk_counts[blockIdx.x] = tot;
 }
 
@@ -157,12 +214,11 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *text, uint64_t 
 __global__ __launch_bounds__(256) void k_line_starts(const uint8_t *text, uint64_t nbytes, const uint32_t *chunk_prefix,
                                                       uint32_t *line_start)
 {
-    typedef hipcub::BlockScan<uint32_t, 256> BS;
-    __shared__ typename BS::TempStorage tmp;
+    __shared__ uint32_t lds[F2Q_SCAN_THREADS / 64 + 1];
     const uint64_t pos = (uint64_t)blockIdx.x * F2Q_NL_CHUNK + threadIdx.x * 16u;
     uint32_t m = nl_mask16(gp(text), pos, nbytes);
-    uint32_t before = 0;
-    BS(tmp).ExclusiveSum((uint32_t)__popc(m), before);
+    uint32_t unused_total;
+    const uint32_t before = block_exclusive_scan((uint32_t)__popc(m), lds, unused_total);
     uint32_t k = chunk_prefix[blockIdx.x] + before + 1u;
     while (m) { const uint32_t b = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u; gpw(line_start)[k++] = (uint32_t)(pos + b + 1u); }
     if (blockIdx.x == 0 && threadIdx.x == 0) gpw(line_start)[0] = 0u;

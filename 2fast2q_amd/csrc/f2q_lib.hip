@@ -1,7 +1,6 @@
 // f2q_lib.hip -- libf2q_hip.so: the one translation unit.  Kernels live in f2q_count_kernels.h and
 // f2q_aux_kernels.h, the per-lane logic in f2q_device.h; this file holds the host side and the C ABI of include/f2q.h.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1082,6 +1081,21 @@ static int block_from_records(f2q_ctx *c, const std::vector<Rec> &recs, f2q_bloc
 }
 
 
+// out[i] = in[0] + ... + in[i-1] on the context's stream (k_scan_blocks / k_scan_sums / k_scan_add)
+static int exclusive_scan(f2q_ctx *c, const uint32_t *in, uint32_t *out, uint32_t n, std::vector<void *> &tmp)
+{
+    if (!n) return F2Q_OK;
+    const uint32_t n_blocks = (n + F2Q_SCAN_BLOCK - 1u) / F2Q_SCAN_BLOCK;
+    uint32_t *sums;
+    int rc = dev_alloc(c, (size_t)n_blocks, &sums, tmp);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(n_blocks), dim3(F2Q_SCAN_THREADS), 0, c->stream, in, out, n, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(F2Q_SCAN_THREADS), 0, c->stream, sums, n_blocks);
+    hipLaunchKernelGGL(k_scan_add, dim3(n_blocks), dim3(F2Q_SCAN_THREADS), 0, c->stream, out, n, sums);
+    HIPC(c, hipGetLastError());
+    return F2Q_OK;
+}
+
 // FASTQ text -> resident block, framing and packing done by the device (k_nl_count .. k_pack).  Handles up to
 // 2 GiB of text per call; *consumed = bytes up to the end of the last complete record.
 // text that is already (on its way) in device memory: `buf` is the allocation (it becomes the block's), `text` the
@@ -1114,11 +1128,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     if (c->trace) { ING(hipStreamSynchronize(c->stream)); c->tr_copy += now_ms() - tc0; }
     hipLaunchKernelGGL(k_nl_count, dim3(n_chunks), dim3(256), 0, c->stream, d_text, (uint64_t)nbytes, d_cc);
     ING(hipGetLastError());
-    size_t cub_bytes = 0;
-    ING(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, d_cc, d_cp, (int)n_chunks + 1, c->stream));
-    uint8_t *d_cub;
-    if ((rc = dev_alloc(c, cub_bytes + 16, &d_cub, tmp))) return bail(rc);
-    ING(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_cc, d_cp, (int)n_chunks + 1, c->stream));
+    if ((rc = exclusive_scan(c, d_cc, d_cp, (uint32_t)n_chunks + 1u, tmp))) return bail(rc);
     uint32_t n_newlines = 0;
     ING(hipMemcpyAsync(&n_newlines, d_cp + n_chunks, 4, hipMemcpyDeviceToHost, c->stream));
     ING(hipStreamSynchronize(c->stream));
@@ -1149,11 +1159,7 @@ static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbyte
     const unsigned igrid = (unsigned)((n_rec + F2Q_ING_THREADS - 1u) / F2Q_ING_THREADS);
     hipLaunchKernelGGL(k_classify, dim3(igrid), dim3(F2Q_ING_THREADS), 0, c->stream, ing, c->plan);
     ING(hipGetLastError());
-    size_t cub2 = 0;
-    ING(hipcub::DeviceScan::ExclusiveSum(nullptr, cub2, ing.clean, d_before, (int)n_rec + 1, c->stream));
-    uint8_t *d_cub2;
-    if ((rc = dev_alloc(c, cub2 + 16, &d_cub2, tmp))) return bail(rc);
-    ING(hipcub::DeviceScan::ExclusiveSum(d_cub2, cub2, ing.clean, d_before, (int)n_rec + 1, c->stream));
+    if ((rc = exclusive_scan(c, ing.clean, d_before, n_rec + 1u, tmp))) return bail(rc);
     uint32_t n_clean = 0, rmax_in = 0;
     ING(hipMemcpyAsync(&n_clean, d_before + n_rec, 4, hipMemcpyDeviceToHost, c->stream));
     ING(hipMemcpyAsync(&rmax_in, ing.meta, 4, hipMemcpyDeviceToHost, c->stream));
