@@ -284,7 +284,7 @@ class Counter:
         self._check(rc)
         return t.as_dict(), False
 
-    # -- a plain file shared out by pieces: nobody reads foreign bytes (include/f2q.h, f2q_file_pieces ...) --
+    # -- a plain or BGZF file shared out by pieces: nobody reads or inflates foreign bytes (include/f2q.h, f2q_file_pieces ...) --
     def file_pieces(self, path, piece_bytes):
         """(number of pieces, shardable)"""
         n, ok = C.c_uint64(), C.c_int()

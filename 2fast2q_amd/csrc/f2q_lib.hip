@@ -1527,16 +1527,52 @@ static inline PieceSpan piece_span(uint64_t file_size, uint64_t piece_bytes, uin
     return PieceSpan{base, base < file_size ? std::min<uint64_t>(piece_bytes, file_size - base) : 0};
 }
 
+// how a file is cut: plain files by byte ranges; BGZF files by runs of whole members whose text adds up to at most
+// piece_bytes (a member is <= 64 KiB of text and carries its text size in its trailer, so the cut needs no inflating)
+struct PieceMap {
+    bool bgzf = false;
+    uint64_t n = 0, max_text = 0;
+    std::vector<uint64_t> c_off, text;                     // BGZF: compressed offset of the piece's first member, its text bytes
+};
+static int piece_map(TextSource &src, const char *path, uint64_t piece_bytes, PieceMap &pm)
+{
+    pm = PieceMap();
+    if (src.kind == TextSource::PLAIN && src.regular) {
+        pm.n = (src.file_size + piece_bytes - 1) / piece_bytes; pm.max_text = std::min<uint64_t>(piece_bytes, src.file_size);
+        return F2Q_OK;
+    }
+    if (!(src.kind == TextSource::BGZF && src.regular)) return F2Q_EUNSUPPORTED;
+    // (the three calls of a run ask for the same map: keep the last one)
+    static std::mutex mu; static std::string last_key; static PieceMap last;
+    struct stat sb; if (stat(path, &sb) != 0) return F2Q_EIO;
+    const std::string key = std::string(path) + "|" + std::to_string((unsigned long long)sb.st_size) + "|" + std::to_string((long long)sb.st_mtime) +
+                            "|" + std::to_string((unsigned long long)piece_bytes);
+    { std::lock_guard<std::mutex> g(mu); if (key == last_key) { pm = last; return F2Q_OK; } }
+    std::vector<uint64_t> off; std::vector<uint32_t> isz;
+    if (!src.bgzf_index(off, isz)) return F2Q_EUNSUPPORTED;
+    pm.bgzf = true;
+    uint64_t acc = 0;
+    for (size_t i = 0; i < off.size(); i++) {
+        if (pm.c_off.empty() || acc + isz[i] > piece_bytes) {
+            if (!pm.c_off.empty() && acc == 0) { pm.c_off.back() = pm.c_off.back(); }      // (an empty run keeps its place)
+            pm.c_off.push_back(off[i]); pm.text.push_back(0); acc = 0;
+        }
+        acc += isz[i]; pm.text.back() = acc;
+    }
+    pm.n = pm.c_off.size();
+    for (uint64_t t : pm.text) pm.max_text = std::max(pm.max_text, t);
+    { std::lock_guard<std::mutex> g(mu); last_key = key; last = pm; }
+    return F2Q_OK;
+}
+
 extern "C" int f2q_file_pieces(const char *path, uint64_t piece_bytes, uint64_t *n_pieces, int *shardable)
 {
     if (!path || !n_pieces || !shardable || piece_bytes < 4096) return F2Q_EINVAL;
     *n_pieces = 0; *shardable = 0;
     TextSource src; std::string err;
     if (src.open(path, err) != 0) { g_create_err = err; return F2Q_EIO; }
-    if (src.kind == TextSource::PLAIN && src.regular) {
-        *shardable = 1;
-        *n_pieces = (src.file_size + piece_bytes - 1) / piece_bytes;
-    }
+    PieceMap pm;
+    if (piece_map(src, path, piece_bytes, pm) == F2Q_OK) { *shardable = pm.bgzf ? 2 : 1; *n_pieces = pm.n; }
     return F2Q_OK;
 }
 
@@ -1546,7 +1582,24 @@ extern "C" int f2q_census_pieces(const char *path, uint32_t rank, uint32_t world
     if (!path || !census || world == 0 || rank >= world || piece_bytes < 4096) return F2Q_EINVAL;
     TextSource src; std::string err;
     if (src.open(path, err) != 0) { g_create_err = err; return F2Q_EIO; }
-    if (!(src.kind == TextSource::PLAIN && src.regular)) { g_create_err = "not a plain regular file"; return F2Q_EUNSUPPORTED; }
+    PieceMap pm;
+    if (piece_map(src, path, piece_bytes, pm) != F2Q_OK || pm.n != n_pieces) { g_create_err = "not a plain or BGZF regular file (or the pieces changed)"; return F2Q_EUNSUPPORTED; }
+    if (pm.bgzf) {
+        // inflate this rank's runs of members (the reader's member-parallel decoder) and count
+        std::vector<uint8_t> b((size_t)std::min<uint64_t>(std::max<uint64_t>(pm.max_text, 1 << 16), (uint64_t)64 << 20));
+        for (uint64_t k = rank; k < n_pieces; k += world) {
+            uint64_t left = pm.text[k], nl = 0; uint8_t lastb = 0;
+            if (!src.seek_bgzf(pm.c_off[k])) { g_create_err = "seek"; return F2Q_EIO; }
+            while (left) {
+                const size_t n = src.read(b.data(), (size_t)std::min<uint64_t>(b.size(), left));
+                if (n == 0) { g_create_err = "BGZF member damaged or cut off"; return F2Q_EIO; }
+                for (size_t j = 0; j < n; j++) nl += (b[j] == 0x0a);
+                lastb = b[n - 1]; left -= n;
+            }
+            census[2 * k] = nl; census[2 * k + 1] = (pm.text[k] && lastb == 0x0a) ? 1 : 0;
+        }
+        return F2Q_OK;
+    }
     const int T = src.n_threads;
     const size_t SL = (size_t)4 << 20;                                  // bytes per pread
     std::vector<std::vector<uint8_t>> bufs((size_t)T);
@@ -1591,16 +1644,20 @@ extern "C" int f2q_count_pieces(f2q_ctx *c, const char *path, uint32_t rank, uin
     HIPC(c, hipSetDevice(c->device));
     TextSource src;
     { std::string err; if (src.open(path, err) != 0) return fail(c, F2Q_EIO, err); }
-    if (!(src.kind == TextSource::PLAIN && src.regular)) return fail(c, F2Q_EUNSUPPORTED, "f2q_count_pieces takes a plain regular file");
-    if (n_pieces != (src.file_size + piece_bytes - 1) / piece_bytes) return fail(c, F2Q_EINVAL, "census does not fit the file");
+    PieceMap pm;
+    if (piece_map(src, path, piece_bytes, pm) != F2Q_OK) return fail(c, F2Q_EUNSUPPORTED, "f2q_count_pieces takes a plain or a BGZF regular file");
+    if (n_pieces != pm.n) return fail(c, F2Q_EINVAL, "census does not fit the file");
     // what this rank owns: for every piece the text offset of its first record start, the number of records, the read index
     struct Job { uint64_t k, skip_lines, n_records, first_read; bool at_line_start; };
     std::vector<Job> jobs;
     {
         uint64_t lines_before = 0;                         // newlines before the piece = index of the line its first byte is in
+        bool prev_ends_nl = true;                          // (the text before the piece ends with a newline, or there is none)
         for (uint64_t k = 0; k < n_pieces; k++) {
-            const bool at_start = k == 0 || census[2 * (k - 1) + 1] != 0;
+            const bool at_start = prev_ends_nl;
             const uint64_t nl = census[2 * k], last_nl = census[2 * k + 1];
+            if (pm.bgzf ? pm.text[k] != 0 : piece_span(src.file_size, piece_bytes, k).size != 0) prev_ends_nl = last_nl != 0;
+            else continue;                                 // an empty piece starts no line
             const uint64_t starts = (at_start ? 1 : 0) + nl - (last_nl ? 1 : 0);          // lines that START in the piece
             const uint64_t i0 = at_start ? lines_before : lines_before + 1;              // index of the first of them
             const uint64_t r0 = (i0 + 3) / 4 * 4;                                        // first record start at or after it
@@ -1615,7 +1672,7 @@ extern "C" int f2q_count_pieces(f2q_ctx *c, const char *path, uint32_t rank, uin
     constexpr int NSLOT = 3;
     PinBuf buf[NSLOT];
     auto drop = [&]() { for (auto &b : buf) g_pinned.release(b); };
-    const size_t cap = HEAD + (size_t)std::min<uint64_t>(piece_bytes, std::max<uint64_t>(src.file_size, 4096)) + MARGIN;
+    const size_t cap = HEAD + (size_t)std::max<uint64_t>(pm.max_text, 4096) + MARGIN + (pm.bgzf ? (size_t)1 << 16 : 0);
     for (auto &b : buf) if (!g_pinned.acquire(cap, b)) { drop(); return fail(c, F2Q_ENOMEM, "cannot allocate the read buffers"); }
     const bool can_stage = !c->host_pack && !getenv("F2Q_NO_STAGING");
     if (can_stage && !c->copy_stream) {
@@ -1633,17 +1690,35 @@ extern "C" int f2q_count_pieces(f2q_ctx *c, const char *path, uint32_t rank, uin
             Piece pc{slot, 0, 0, 0, 0, true};
             if (j < jobs.size()) {
                 const Job &jb = jobs[j];
-                const PieceSpan sp = piece_span(src.file_size, piece_bytes, jb.k);
-                const uint64_t want = std::min<uint64_t>(sp.size + MARGIN, src.file_size - sp.base);
+                PieceSpan sp = piece_span(src.file_size, piece_bytes, jb.k);
+                uint64_t want = std::min<uint64_t>(sp.size + MARGIN, src.file_size - sp.base);
                 uint8_t *p = buf[slot].p + HEAD;
-                const size_t n = src.read_at(sp.base, p, (size_t)want);
-                pc.ok = n == want;
+                size_t n = 0;
+                if (!pm.bgzf) { n = src.read_at(sp.base, p, (size_t)want); pc.ok = n == want; }
+                else {
+                    // the run of members, then members behind it until the last record is whole (4 newlines) or the margin is full
+                    sp.base = 0; sp.size = pm.text[jb.k];
+                    pc.ok = src.seek_bgzf(pm.c_off[jb.k]);
+                    while (pc.ok && n < sp.size) { const size_t g = src.read(p + n, (size_t)(sp.size - n)); if (!g) pc.ok = false; n += g; }
+                    size_t seen = 0, o = n;
+                    bool more = true;
+                    while (pc.ok && more && seen < 4 && n < sp.size + MARGIN) {
+                        const size_t g = src.read(p + n, (size_t)std::min<uint64_t>((uint64_t)1 << 16, sp.size + MARGIN - n));
+                        if (!g) { more = false; if (src.truncated()) pc.ok = false; break; }
+                        n += g;
+                        while (seen < 4 && o < n) { const uint8_t *q = (const uint8_t *)memchr(p + o, 0x0a, n - o); if (!q) { o = n; break; } o = (size_t)(q - p) + 1; seen++; }
+                    }
+                    // (for the check below: "the file goes on behind what was read" <=> the margin filled up without 4 newlines)
+                    want = n; sp.base = 0;
+                    const bool file_goes_on = more && seen < 4;
+                    if (file_goes_on) pc.ok = false;
+                }
                 // the first record start: the line after the one cut by the piece's start, then `skip_lines` more
                 size_t a = 0;
                 uint64_t skip = jb.skip_lines + (jb.at_line_start ? 0 : 1);
                 while (skip && a < n) { const uint8_t *q = (const uint8_t *)memchr(p + a, 0x0a, n - a); if (!q) { a = n; break; } a = (size_t)(q - p) + 1; skip--; }
                 // the margin must hold the rest of the last record (4 more newlines, or the end of the file)
-                if (sp.base + want < src.file_size) {
+                if (!pm.bgzf && sp.base + want < src.file_size) {
                     size_t seen = 0, o = (size_t)sp.size;
                     while (seen < 4 && o < n) { const uint8_t *q = (const uint8_t *)memchr(p + o, 0x0a, n - o); if (!q) break; o = (size_t)(q - p) + 1; seen++; }
                     if (seen < 4) pc.ok = false;           // lines too long for the margin: the caller falls back

@@ -126,6 +126,42 @@ struct TextSource {
         return read_plain(dst, cap);
     }
 
+    // BGZF regular files: start over at the member that begins at compressed offset `off`
+    bool seek_bgzf(uint64_t off)
+    {
+        if (kind != BGZF || !regular) return false;
+        file_pos = off; cbuf.clear(); cpos = 0; c_eof = false; spill.clear(); spill_pos = 0; bad = false; done = false;
+        return true;
+    }
+    // BGZF regular files: compressed offset and text bytes of every member, in file order.  false: some member is not
+    // a BGZF member (ordinary gzip appended, damage) -- such a file is read front to back only.
+    bool bgzf_index(std::vector<uint64_t> &off, std::vector<uint32_t> &isz)
+    {
+        off.clear(); isz.clear();
+        if (kind != BGZF || !regular) return false;
+        const size_t CH = (size_t)8 << 20;
+        std::vector<uint8_t> b(CH + 65536 + 64);
+        uint64_t pos = 0;                                   // compressed offset of the next member
+        while (pos < file_size) {
+            const size_t want = (size_t)std::min<uint64_t>(b.size(), file_size - pos);
+            size_t n = 0;
+            while (n < want) { ssize_t r = pread(fd, b.data() + n, want - n, (off_t)(pos + n)); if (r <= 0) return false; n += (size_t)r; }
+            size_t o = 0;
+            while (o < n) {
+                uint32_t bsize;
+                if (n - o < 18 || !bgzf_header(b.data() + o, n - o, bsize)) { if (n - o >= 18 || pos + n >= file_size) return false; break; }
+                if (n - o < bsize) { if (pos + n >= file_size) return false; break; }      // member continues in the next chunk
+                const uint8_t *t = b.data() + o + bsize - 4;
+                off.push_back(pos + o); isz.push_back(t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24));
+                o += bsize;
+                if (o >= CH) break;
+            }
+            if (o == 0) return false;
+            pos += o;
+        }
+        return true;
+    }
+
 private:
     // continue (or start) as ordinary gzip from compressed offset `from`
     int open_gzip(uint64_t from, std::string &err)

@@ -95,7 +95,7 @@ PIECE_BYTES = 256 << 20
 def count_file_sharded(ctx, path, w, block_bytes=BLOCK_BYTES):
     """rank w.rank counts its blocks of `path` into ctx; returns the truncated-gzip flag"""
     if hasattr(ctx, "count_pieces"):
-        # plain files: every rank reads only its own pieces.  The 4-line framing is global, so the ranks first pool the
+        # plain and BGZF files: every rank reads (and inflates) only its own pieces.  The 4-line framing is global, so the ranks first pool the
         # line counts of their pieces (one small all-reduce), then each frames its share on its own (include/f2q.h)
         piece = int(os.environ.get("F2Q_PIECE_BYTES", PIECE_BYTES))
         n_pieces, ok = ctx.file_pieces(path, piece)

@@ -136,10 +136,14 @@ int f2q_count_file(f2q_ctx *ctx, const char *path, f2q_timing *t);
  * The sum over the ranks of counts and stats equals f2q_count_file's. */
 int f2q_count_file_shard(f2q_ctx *ctx, const char *path, uint32_t rank, uint32_t world, f2q_timing *t);
 
-/* The same job without any rank reading another rank's bytes (plain, regular files): the file is cut into pieces of
- * piece_bytes (>= 4096), piece k belongs to rank k % world.  The 4-line framing is global, so the ranks first exchange
- * how many lines each piece holds:
- *   1. f2q_file_pieces   -- number of pieces; *shardable = 0 for gzip/BGZF/pipes (use f2q_count_file_shard there)
+/* The same job without any rank reading -- or inflating -- another rank's share (regular files, plain or BGZF): the
+ * file is cut into pieces, piece k belongs to rank k % world.  Plain: byte ranges of piece_bytes (>= 4096).  BGZF: runs
+ * of whole members whose text adds up to at most piece_bytes (every member carries its compressed size in the header
+ * and its text size in the trailer, so the cut needs no inflating); a rank inflates only its own runs -- once for the
+ * census, once to count -- plus the few members behind a run that finish its last record.  The 4-line framing is
+ * global, so the ranks first exchange how many lines each piece holds:
+ *   1. f2q_file_pieces   -- number of pieces; *shardable = 1 plain, 2 BGZF, 0 for ordinary gzip / pipes / BGZF with
+ *                           other members inside (use f2q_count_file_shard there)
  *   2. f2q_census_pieces -- census[2k] = newlines of piece k, census[2k+1] = 1 if it ends with one, for THIS rank's pieces
  *                           (the other entries are left as they are: pass a zeroed vector)
  *   3. the caller sums the census vectors over the ranks (one all-reduce of 2 * n_pieces uint64)

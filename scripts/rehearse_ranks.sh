@@ -63,3 +63,29 @@ grep -h "Sample big was processed" $O/big_one.log $O/big_rank0.log $O/big_rank1.
 A=$(find $W/bone -name "one.csv" | head -1); B=$(find $W/btwo -name "two.csv" | head -1)
 if [ -n "$A" ] && [ -n "$B" ] && cmp $A $B; then echo "big file: compiled tables identical ($(wc -l < $A) rows), each rank read only its own pieces" | tee -a $O/progress.txt; else echo "big file: tables differ or missing [$A] [$B]" | tee -a $O/progress.txt; tail -20 $O/big_rank0.log; fi
 true
+# ... and on a BGZF file of the same reads: every rank inflates only its own runs of members (census + count)
+python - "$W" <<'PY'
+import sys, os
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+from conftest import bgzf_bytes
+w = sys.argv[1]
+os.makedirs(w + "/bz")
+fq = open(w + "/big/big.fastq", "rb").read()[: 400 << 20]
+fq = fq[: fq.rfind(b"\n@") + 1]
+open(w + "/bz/bz.fastq.gz", "wb").write(bgzf_bytes(fq, level=1))
+PY
+export F2Q_PIECE_BYTES=33554432
+t0=$(date +%s%N)
+timeout -s ABRT -k 5 200 python -m 2fast2q_amd -c --s $W/bz --g $W/g.csv --o $W/zone --fn one --m 1 --pb > $O/bz_one.log 2>&1
+t1=$(date +%s%N); echo "BGZF, one process: $(( (t1 - t0) / 1000000 )) ms wall" > $O/time_bz_one.txt
+for r in 0 1; do
+  RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29523 F2Q_DEVICE=0 F2Q_DIST_BACKEND=gloo \
+    timeout -s ABRT -k 5 200 python -m 2fast2q_amd -c --s $W/bz --g $W/g.csv --o $W/ztwo --fn two --m 1 --pb > $O/bz_rank$r.log 2>&1 &
+done
+t0=$(date +%s%N); wait; t1=$(date +%s%N)
+echo "BGZF, two ranks: $(( (t1 - t0) / 1000000 )) ms wall" > $O/time_bz_two.txt
+cat $O/time_bz_one.txt $O/time_bz_two.txt | tee -a $O/progress.txt
+grep -h "Sample bz was processed" $O/bz_one.log $O/bz_rank0.log $O/bz_rank1.log | tee -a $O/progress.txt
+A=$(find $W/zone -name "one.csv" | head -1); B=$(find $W/ztwo -name "two.csv" | head -1)
+if [ -n "$A" ] && [ -n "$B" ] && cmp $A $B; then echo "BGZF file: compiled tables identical ($(wc -l < $A) rows), each rank inflated only its own runs of members" | tee -a $O/progress.txt; else echo "BGZF file: tables differ or missing [$A] [$B]" | tee -a $O/progress.txt; tail -20 $O/bz_rank0.log; fi
+true

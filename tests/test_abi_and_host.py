@@ -35,6 +35,38 @@ def test_library_exports_every_declared_symbol():
     assert binding.build_id() == g.source_id()
 
 
+def test_bgzf_pieces_and_census_on_the_host(tmp_path):
+    """f2q_file_pieces / f2q_census_pieces need no device: a BGZF file is cut into runs of whole members from the text
+    sizes in the member trailers, and the census of all runs adds up to the newlines of the text"""
+    import ctypes as C
+    import gzip
+    import numpy as np
+    from conftest import bgzf_bytes
+    import __graft_entry__ as g
+    g.build()
+    L = binding.load()
+    text = b"".join(b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(30000))
+    path = tmp_path / "x.fastq.gz"
+    path.write_bytes(bgzf_bytes(text[:400000], block=5000, eof_marker=True) + bgzf_bytes(text[400000:], block=0xFF00))
+    for piece in (4096, 100000, 1 << 22):
+        n, ok = C.c_uint64(), C.c_int()
+        assert L.f2q_file_pieces(os.fsencode(str(path)), piece, C.byref(n), C.byref(ok)) == 0
+        assert ok.value == 2 and n.value >= 1
+        total = np.zeros(2 * n.value, dtype=np.uint64)
+        for world in (1, 3):
+            total[:] = 0
+            for rank in range(world):
+                cen = np.zeros(2 * n.value, dtype=np.uint64)
+                assert L.f2q_census_pieces(os.fsencode(str(path)), rank, world, piece, cen.ctypes.data_as(C.POINTER(C.c_uint64)), n.value) == 0
+                total += cen
+            assert int(total[0::2].sum()) == text.count(b"\n")
+    plain = tmp_path / "x.fastq"; plain.write_bytes(text)
+    n, ok = C.c_uint64(), C.c_int()
+    assert L.f2q_file_pieces(os.fsencode(str(plain)), 1 << 16, C.byref(n), C.byref(ok)) == 0 and ok.value == 1
+    other = tmp_path / "y.fastq.gz"; other.write_bytes(gzip.compress(text))
+    assert L.f2q_file_pieces(os.fsencode(str(other)), 1 << 16, C.byref(n), C.byref(ok)) == 0 and ok.value == 0 and n.value == 0
+
+
 def test_build_sees_every_source_file():
     import __graft_entry__ as g
     deps = {os.path.basename(d) for d in g.hip_deps()}

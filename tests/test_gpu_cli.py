@@ -139,6 +139,52 @@ def test_count_file_shard_sums_to_the_whole(tmp_path, monkeypatch, kind, world):
             assert [(k, n) for k, n, _ in sharding.merge_ec_tables(tables)] == list(zip(orc.keys(), orc.counts()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,piece,block", [(2, 1 << 16, 20000), (3, 200000, 0xFF00), (4, 4096, 3000), (1, 1 << 20, 0xFF00)])
+def test_count_pieces_of_a_bgzf_file(tmp_path, world, piece, block):
+    """the same protocol on a BGZF file: a piece is a run of whole members (their text sizes come from the trailers), each
+    rank inflates only its own runs -- once for the census, once to count -- plus the members behind a run that finish its
+    last record.  Empty members inside the file, a partial last record, ordinary gzip refused."""
+    sharding = importlib.import_module("2fast2q_amd.sharding")
+    guides = synth.make_library(150, 20, 5)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=34, n_reads=7000, read_len=101), guides), 3, rate=0.004)
+    fq = fq.replace(b"\n", b"\r\n", 300) + b"@tail\nACGT"
+    cut = len(fq) // 3
+    raw = bgzf_bytes(fq[:cut], block=block, eof_marker=True) + bgzf_bytes(fq[cut:], block=block)     # an empty member in the middle
+    path = tmp_path / "s.fastq.gz"
+    path.write_bytes(raw)
+    for kw in (dict(miss=1), dict(mode="EC", upstream="ACGT", length=9)):
+        feats = guides if "mode" not in kw else None
+        orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)] if feats else None, **kw)
+        orc.count_fastq(fq)
+        ctxs = [pkg().Counter(features=feats, **kw) for _ in range(world)]
+        n_pieces, ok = ctxs[0].file_pieces(str(path), piece)
+        assert ok and n_pieces >= max(1, len(fq) // max(piece, block + 1) // 2)
+        census = sum(c.census_pieces(str(path), r, world, piece, n_pieces) for r, c in enumerate(ctxs))
+        assert int(census[0::2].sum()) == fq.count(b"\n")
+        tot_counts, tot_stats, tables, reads = None, [0] * 5, [], 0
+        for r, c in enumerate(ctxs):
+            t = c.count_pieces(str(path), r, world, piece, census)
+            counts, stats = c.read_counts()
+            reads += t["reads"]
+            tot_stats = [a + int(b) for a, b in zip(tot_stats, stats)]
+            if feats:
+                tot_counts = list(counts) if tot_counts is None else [a + b for a, b in zip(tot_counts, counts)]
+            else:
+                tables.append(c.ec_results())
+            c.close()
+        assert tot_stats == orc.stats() and reads == orc.stats()[0]
+        if feats:
+            assert tot_counts == orc.counts()
+        else:
+            assert [(k, n) for k, n, _ in sharding.merge_ec_tables(tables)] == list(zip(orc.keys(), orc.counts()))
+    # BGZF that turns into ordinary gzip half way: not shardable (front-to-back reading only)
+    mixed = tmp_path / "m.fastq.gz"
+    mixed.write_bytes(bgzf_bytes(fq[:cut], block=block, eof_marker=False) + gzip.compress(fq[cut:], 1))
+    with pkg().Counter(features=guides) as c:
+        assert c.file_pieces(str(mixed), piece) == (0, False)
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 5])
 @pytest.mark.parametrize("piece", [4096, 50000, 1 << 20])
 def test_count_pieces_without_foreign_bytes(tmp_path, world, piece):
