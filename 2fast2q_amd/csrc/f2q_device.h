@@ -207,7 +207,7 @@ F2Q_HD uint32_t ec64_text(unsigned long long word, char *out)
 #define F2Q_HOT_BUCKETS 4096u
 #define F2Q_HOT_SLOTS (4u * F2Q_HOT_BUCKETS)
 #define F2Q_HOT_CAP 11264u           // keys admitted: load <= 0.69
-#define F2Q_HOT_MINCOUNT 8u          // a key becomes a candidate when the learning reads bring its count to this
+#define F2Q_HOT_MINCOUNT 6u          // a key becomes a candidate when the learning reads bring its count to this
 #define F2Q_HOT_CAND 32768u          // candidates noted (in the order they got there: the most frequent first)
 #define F2Q_HOT_NONE 0xFFFFFFFFu
 #define F2Q_HOT_MAXPROBE 96u         // slots an insert looks at before the read is set aside for a grown table

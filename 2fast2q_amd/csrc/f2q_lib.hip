@@ -84,7 +84,7 @@ struct f2q_ctx {
     EcHot hot{};
     std::vector<void *> hot_allocs;
     bool hot_valid = false, no_hot = false;
-    uint64_t hot_learn = (uint64_t)1 << 19, ec_learned = 0;
+    uint64_t hot_learn = (uint64_t)1 << 18, ec_learned = 0;
     unsigned long long *defer_d = nullptr; size_t defer_cap = 0;
     uint64_t reads_seen = 0;             // global read index of the next block's read 0
     int n_cu = 256;
@@ -998,7 +998,9 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
         t->fast_reads = b->n_reads - b->n_general; t->launches = launches;
     }
-    if (c->prm.mode == 1 && b->n_reads) {
+    if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot)) {
+        // (the hot-key path has looked at the counters after its last launch; what its deferred passes could still
+        // report is seen by the next call that reads them)
         unsigned long long ctr[4];
         HIPC(c, hipMemcpyAsync(ctr, c->ec.ctr, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
