@@ -974,6 +974,75 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
     }
 }
 
+// ---- several --us/--ds pairs (pairs_lane, f2q_device.h) ---------------------------------------------------------------
+// k_count_anchor's tile walk; every pair is searched on the planes the lane already holds, the joined key is matched as
+// a string (byte-string index, or the 2-bit tables when neither key nor library holds a ':').  Counter mode counts in an
+// LDS histogram when the library fits, Extract+Count inserts in place (the host reserves for every read of the view).
+template <int NW, int KB, bool SAMEQ, bool USE_LDS>
+__global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor_pairs(const RunDev *__restrict__ runp, const LibDev *__restrict__ libp,
+                                                                       EcDev ec, PackedBlock pb, Accum acc, uint64_t read_base)
+{
+    constexpr int NQW = 8 * NW;
+    extern __shared__ uint32_t pairs_hist[];
+    __shared__ __attribute__((aligned(4))) uint8_t pairs_keys[F2Q_AN_THREADS * F2Q_PAIRS_KEYMAX];
+    uint8_t *kb = pairs_keys + threadIdx.x * F2Q_PAIRS_KEYMAX;
+    const RunDev &run = *runp;
+    const LibDev &lib = *libp;
+    const uint32_t nf = lib.n_features, tid = threadIdx.x;
+    if (USE_LDS) for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) pairs_hist[i] = 0;
+    __syncthreads();
+    const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    uint32_t n_new = 0;
+    for (uint32_t tile = blockIdx.x; tile < pb.n_tiles; tile += gridDim.x) {
+        const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
+        const uint32_t l = pb.len ? gp(pb.len)[slot] : pb.rmax;
+        const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + tid;
+        const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + tid;
+        uint32_t LO[NW], HI[NW], Q[NQW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) { LO[w] = __builtin_nontemporal_load(bp + (uint64_t)w * F2Q_TILE); HI[w] = __builtin_nontemporal_load(bp + (uint64_t)(NW + w) * F2Q_TILE); }
+#pragma unroll
+        for (int i = 0; i < NQW; i++) Q[i] = __builtin_nontemporal_load(qp + (uint64_t)i * F2Q_TILE);
+        if (l == F2Q_LEN_SKIP) continue;
+        const bool flagged = (l & F2Q_LEN_FLAG) != 0;
+        uint32_t FW[NW], FU[SAMEQ ? 1 : NW], FD[SAMEQ ? 1 : NW], FLG[NW];
+#pragma unroll
+        for (int cw = 0; cw < NW; cw++) {
+            uint32_t q8[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) q8[i] = Q[8 * cw + i];
+            FW[cw] = fail_word8(q8, ah_w);
+            if (!SAMEQ) { FU[cw] = fail_word8(q8, ah_u); FD[cw] = fail_word8(q8, ah_d); }
+            FLG[cw] = flagged ? flag_word8(q8) : 0u;
+        }
+        const int r = (int)(l & 0x7FFFu);
+        const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+        uint32_t idx = 0;
+        int res;
+        if constexpr (SAMEQ) res = pairs_lane<NW, KB>(run, lib, ec, kb, LO, HI, FLG, r, FW, FW, FW, gi, idx, &n_new);
+        else res = pairs_lane<NW, KB>(run, lib, ec, kb, LO, HI, FLG, r, FU, FD, FW, gi, idx, &n_new);
+        if (res < 0) {
+            const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
+            anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st);
+            continue;
+        }
+        st[0]++;
+        if (res == 0) st[1]++;                                   // Extract+Count: the key went into a table (:387)
+        else {
+            st[res]++;
+            if (res == 1 || res == 2) { if (USE_LDS) atomicAdd(&pairs_hist[idx], 1u); else acc_add(&acc.counts[idx], 1ull); }
+        }
+    }
+    if (run.mode == 1) ec64_report_new(ec, n_new);
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
+    if (USE_LDS) {
+        __syncthreads();
+        for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) { const uint32_t n = pairs_hist[i]; if (n) acc_add(&acc.counts[i], (unsigned long long)n); }
+    }
+}
+
 // ---- anchored runs with the library in LDS ---------------------------------------------------------------------
 // k_count_anchor's extraction stage (bit-plane tiles, bit-parallel anchor search, fail vectors) in front of
 // k_count_fixed4_lds's matching stage: Counter mode, uniform library of 14..21-base features, --m <= 1.  Every window

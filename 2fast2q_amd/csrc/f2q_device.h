@@ -60,6 +60,9 @@ struct RunDev {
     int32_t pad_;
     uint64_t up_codes, down_codes;     // symbol j = (codes >> 2j) & 3  -- one scalar load, no per-symbol memory access
     uint32_t up_pos[4], down_pos[4];   // per symbol c: bit j set iff anchor symbol j == c
+    // several --us/--ds pairs, every anchor ACGT-only and 1..32 long: the same masks per pair (k_count_anchor_pairs)
+    int32_t pairs_packed, pad2_;
+    uint32_t mp_up_pos[F2Q_DEV_MAX_ITER][4], mp_down_pos[F2Q_DEV_MAX_ITER][4];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -106,7 +109,11 @@ struct GkGroup {
     uint32_t piece_off[F2Q_GK_MAXP];
     uint32_t cut[F2Q_GK_MAXP + 1];     // piece p = bytes [cut[p], cut[p+1])
 };
-struct GkDesc { uint32_t n_groups, pad; const GkGroup *grp; const uint32_t *tab; const uint32_t *ids; };
+// fw / fwoff: every feature's bytes again as little-endian 8-byte words, zero padded (feature f at fw[fwoff[f]]): a
+// candidate is checked with (len + 7) / 8 independent loads instead of a byte loop with an early exit
+#define F2Q_GK_MAXW 13             // keys of up to 104 bytes take the word path
+struct GkDesc { uint32_t n_groups, pad; const GkGroup *grp; const uint32_t *tab; const uint32_t *ids;
+                const unsigned long long *fw; const uint32_t *fwoff; };
 
 // multi-window runs (--st a,b,...): a key is the ':'-joined windows that passed their Phred test (fast2q.py:349-363);
 // features made of k ACGT runs of --l bases joined by ':' ("k-part features") are indexed by their k*l bases
@@ -443,6 +450,41 @@ F2Q_HD const GkGroup *gk_find(const LibDev &lib, int len)
     }
     return nullptr;
 }
+// the key as words (see GkDesc::fw), for keys of at most 8 * F2Q_GK_MAXW bytes
+struct GkKey { unsigned long long w[F2Q_GK_MAXW]; };
+template <class KV>
+F2Q_HD void gk_key_words(const KV &kv, GkKey &k)
+{
+#pragma unroll
+    for (int wi = 0; wi < F2Q_GK_MAXW; wi++) {
+        unsigned long long v = 0;
+        if (8 * wi < kv.len) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) if (8 * wi + b < kv.len) v |= (unsigned long long)kv.at(8 * wi + b) << (8 * b);
+        }
+        k.w[wi] = v;
+    }
+}
+// bit i of (lo, hi) set <=> byte i of the key differs from byte i of feature f
+F2Q_HD void gk_diff_bytes(const LibDev &lib, const GkKey &k, uint32_t f, int len, unsigned long long &lo, unsigned long long &hi)
+{
+    const auto fw = gp(lib.gk.fw) + gp(lib.gk.fwoff)[f];
+    lo = 0; hi = 0;
+#pragma unroll
+    for (int wi = 0; wi < F2Q_GK_MAXW; wi++) {
+        if (8 * wi < len) {
+            const unsigned long long x = k.w[wi] ^ fw[wi];
+            const unsigned long long nz = ((((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull) >> 7;   // 1 per differing byte
+            const unsigned long long bits = (nz * 0x0102040810204080ull) >> 56;                                                        // the 8 flags side by side
+            if (wi < 8) lo |= bits << (8 * wi); else hi |= bits << (8 * (wi - 8));
+        }
+    }
+}
+F2Q_HD bool gk_range_clear(unsigned long long lo, unsigned long long hi, int a, int b)      // no differing byte in [a, b)
+{
+    for (int i = a; i < b; i++) if (((i < 64 ? lo >> i : hi >> (i - 64)) & 1ull)) return false;
+    return true;
+}
 // exact hit among the features of the group: feature index or -1
 template <class KV>
 F2Q_HD int gk_exact(const LibDev &lib, const GkGroup &g, const KV &kv)
@@ -450,10 +492,17 @@ F2Q_HD int gk_exact(const LibDev &lib, const GkGroup &g, const KV &kv)
     const uint32_t m = (1u << g.bits) - 1u;
     uint32_t s = (uint32_t)(gk_hash_key(kv, 0, kv.len, 0xE0u) >> (64u - g.bits));
     const auto tab = gp(lib.gk.tab);
+    const bool words = kv.len <= 8 * F2Q_GK_MAXW && lib.gk.fw != nullptr;
+    GkKey k;
+    if (words) gk_key_words(kv, k);
     for (;;) {
         const uint32_t e = tab[g.exact_off + s];
         if (e == 0u) return -1;
-        if (gk_range_equal(kv, gp(lib.feat_bytes) + gp(lib.feat_off)[e - 1u], 0, kv.len)) return (int)(e - 1u);
+        if (words) {
+            unsigned long long lo, hi;
+            gk_diff_bytes(lib, k, e - 1u, kv.len, lo, hi);
+            if ((lo | hi) == 0ull) return (int)(e - 1u);
+        } else if (gk_range_equal(kv, gp(lib.feat_bytes) + gp(lib.feat_off)[e - 1u], 0, kv.len)) return (int)(e - 1u);
         s = (s + 1u) & m;
     }
 }
@@ -463,17 +512,31 @@ F2Q_HD void gk_near(const LibDev &lib, const GkGroup &g, const KV &kv, MinTrack 
 {
     const uint32_t m = (1u << g.bits) - 1u;
     const auto tab = gp(lib.gk.tab);
+    const bool words = kv.len <= 8 * F2Q_GK_MAXW && lib.gk.fw != nullptr;
+    GkKey k;
+    if (words) gk_key_words(kv, k);
     for (uint32_t p = 0; p < g.n_pieces; p++) {
         const int a = (int)g.cut[p], b = (int)g.cut[p + 1];
         uint32_t s = (uint32_t)(gk_hash_key(kv, a, b, p) >> (64u - g.bits));
         for (;;) {
             const uint32_t e = tab[g.piece_off[p] + s];
             if (e == 0u) break;
-            gbytes fb = gp(lib.feat_bytes) + gp(lib.feat_off)[e - 1u];
-            if (gk_range_equal(kv, fb, a, b)) {
-                bool dup = false;                              // counted at the first piece it agrees on
-                for (uint32_t q = 0; q < p && !dup; q++) dup = gk_range_equal(kv, fb, (int)g.cut[q], (int)g.cut[q + 1]);
-                if (!dup) { const int d = key_dist(kv, fb, t.best); if (d <= t.best) t.offer(d, e - 1u); }
+            if (words) {
+                unsigned long long lo, hi;
+                gk_diff_bytes(lib, k, e - 1u, kv.len, lo, hi);
+                if (gk_range_clear(lo, hi, a, b)) {
+                    bool dup = false;                          // counted at the first piece it agrees on
+                    for (uint32_t q = 0; q < p && !dup; q++) dup = gk_range_clear(lo, hi, (int)g.cut[q], (int)g.cut[q + 1]);
+                    const int d = popc64(lo) + popc64(hi);
+                    if (!dup && d <= t.best) t.offer(d, e - 1u);
+                }
+            } else {
+                gbytes fb = gp(lib.feat_bytes) + gp(lib.feat_off)[e - 1u];
+                if (gk_range_equal(kv, fb, a, b)) {
+                    bool dup = false;
+                    for (uint32_t q = 0; q < p && !dup; q++) dup = gk_range_equal(kv, fb, (int)g.cut[q], (int)g.cut[q + 1]);
+                    if (!dup) { const int d = key_dist(kv, fb, t.best); if (d <= t.best) t.offer(d, e - 1u); }
+                }
             }
             s = (s + 1u) & m;
         }
@@ -780,6 +843,27 @@ F2Q_HD void ec64_report_new(const EcDev &ec, uint32_t n_new)
 #endif
 }
 
+// Extract+Count: one key of a read.  Keys that have a single-word form (ec64_word) go to that table, every other key to
+// the byte-string table -- one rule for every path, so that a key never sits in both.  n_new: the caller sums new
+// single-word keys and reports them once per wave (ec64_report_new); nullptr: reported here.
+template <class KV>
+F2Q_HD void ec_count_key(const EcDev &ec, const KV &kv, unsigned long long read_index, uint32_t *n_new)
+{
+    bool regular = (kv.nseg == 1 && kv.len <= F2Q_EC64_MAXLEN && ec.k64_slots != nullptr);
+    uint64_t key = 0; uint32_t nmask = 0;
+    for (int j = 0; regular && j < kv.len; j++) {
+        const uint8_t ch = up8(kv.seq[kv.a[0] + j]);
+        uint32_t c = base_code(ch);
+        if (c > 3u) { if (ch == (uint8_t)'N') { nmask |= 1u << j; c = 0; } else regular = false; }
+        key |= (uint64_t)(c & 3u) << (2 * j);
+    }
+    unsigned long long word = 0;
+    regular = regular && ec64_word(key, nmask, kv.len, word);
+    if (regular && n_new) *n_new += ec64_insert_word(ec, word, read_index);
+    else if (regular) { if (ec64_insert_word(ec, word, read_index)) ec_fetch_add(&ec.ctr[3], 1ull); }
+    else ec_insert(ec, kv, read_index);
+}
+
 // ---------------------------------------------------------------------------------------------
 // general path: one read given as raw bytes.  st[] = the 5 reference counters (thread-local).
 // ---------------------------------------------------------------------------------------------
@@ -812,21 +896,7 @@ F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, 
             if (res == 1 || res == 2) acc_add(&acc.counts[idx], 1ull);
             st[res]++;
         } else {
-            // keys that have a single-word form (ec64_word) go to that table, so that a key never sits in both
-            bool regular = (kv.nseg == 1 && kv.len <= F2Q_EC64_MAXLEN && ec.k64_slots != nullptr);
-            uint64_t key = 0; uint32_t nmask = 0;
-            for (int j = 0; regular && j < kv.len; j++) {
-                const uint8_t ch = up8(kv.seq[kv.a[0] + j]);
-                uint32_t c = base_code(ch);
-                if (c > 3u) { if (ch == (uint8_t)'N') { nmask |= 1u << j; c = 0; } else regular = false; }
-                key |= (uint64_t)(c & 3u) << (2 * j);
-            }
-            unsigned long long word = 0;
-            regular = regular && ec64_word(key, nmask, kv.len, word);
-            // n_new: the caller sums new single-word keys and reports them once per wave (ec64_report_new)
-            if (regular && n_new) *n_new += ec64_insert_word(ec, word, read_index);
-            else if (regular) { if (ec64_insert_word(ec, word, read_index)) ec_fetch_add(&ec.ctr[3], 1ull); }
-            else ec_insert(ec, kv, read_index);
+            ec_count_key(ec, kv, read_index, n_new);
             st[1]++;                                                             // :387
         }
     }
@@ -1483,8 +1553,9 @@ F2Q_HD void anchor_compare(const uint32_t (&cnt)[KB > 0 ? KB : 1][NW], const uin
 // anchor that holds the symbol (run.up_pos / run.down_pos are per-symbol position masks), so one plane is
 // live at a time and the scalar loop runs once per anchor symbol.  All loops/branches are wave-uniform.
 template <int NW, int KBU, int KBD>
-F2Q_HD void anchor_hits2(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW],
-                         uint32_t (&hu)[NW], uint32_t (&hd)[NW])
+F2Q_HD void anchor_hits2p(const RunDev &run, const uint32_t *up_pos, const uint32_t *down_pos,
+                          const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW],
+                          uint32_t (&hu)[NW], uint32_t (&hd)[NW])
 {
     uint32_t cu[KBU > 0 ? KBU : 1][NW], ou[NW], cd[KBD > 0 ? KBD : 1][NW], od[NW];
 #pragma unroll
@@ -1501,11 +1572,17 @@ F2Q_HD void anchor_hits2(const RunDev &run, const uint32_t (&LO)[NW], const uint
         uint32_t P[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++) P[w] = (LO[w] ^ la) | (HI[w] ^ ha) | FLG[w];   // 1 = base is not symbol c (flagged: never)
-        if (run.has_up) anchor_steps<NW, KBU>(P, run.up_pos[c], cu, ou);
-        if (run.has_down) anchor_steps<NW, KBD>(P, run.down_pos[c], cd, od);
+        if (run.has_up) anchor_steps<NW, KBU>(P, up_pos[c], cu, ou);
+        if (run.has_down) anchor_steps<NW, KBD>(P, down_pos[c], cd, od);
     }
     anchor_compare<NW, KBU>(cu, ou, run.msu, hu);
     anchor_compare<NW, KBD>(cd, od, run.msd, hd);
+}
+template <int NW, int KBU, int KBD>
+F2Q_HD void anchor_hits2(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW],
+                         uint32_t (&hu)[NW], uint32_t (&hd)[NW])
+{
+    anchor_hits2p<NW, KBU, KBD>(run, run.up_pos, run.down_pos, LO, HI, FLG, hu, hd);
 }
 
 // first set bit at a position in [from, to] (inclusive) or -1
@@ -1592,15 +1669,15 @@ F2Q_HD bool any_fail_short(const uint32_t (&F)[NW], int a, int len)
 }
 
 template <int NW, int KBU, int KBD>
-F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW],
-                               const uint32_t (&FLG)[NW], int r,
-                               const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW])
+F2Q_HD AnchorWin anchor_window_pair(const RunDev &run, int su, int sd, const uint32_t *up_pos, const uint32_t *down_pos,
+                                    const uint32_t (&LO)[NW], const uint32_t (&HI)[NW],
+                                    const uint32_t (&FLG)[NW], int r,
+                                    const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW])
 {
     AnchorWin out; out.ok = 0; out.start = 0; out.end = 0;
-    const int su = run.up_len[0], sd = run.down_len[0];
     int start, end;
     uint32_t hu[NW], hd[NW];
-    anchor_hits2<NW, KBU, KBD>(run, LO, HI, FLG, hu, hd);
+    anchor_hits2p<NW, KBU, KBD>(run, up_pos, down_pos, LO, HI, FLG, hu, hd);
     if (run.has_up && run.has_down) {
         const int pu = first_hit<NW>(hu, 0, r - su);
         if (pu < 0) return out;
@@ -1626,6 +1703,52 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
     out.ok = 1; out.start = start; out.end = end;
     return out;
 }
+template <int NW, int KBU, int KBD>
+F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], const uint32_t (&HI)[NW],
+                               const uint32_t (&FLG)[NW], int r,
+                               const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW])
+{
+    return anchor_window_pair<NW, KBU, KBD>(run, run.up_len[0], run.down_len[0], run.up_pos, run.down_pos, LO, HI, FLG, r, FU, FD, FW);
+}
+
+// One read of a run with several --us/--ds pairs, on the planes (fast2q.py:333-363): every pair is searched on its own,
+// the windows that pass are joined with ':' in pair order, pairs that fail are left out; no window at all counts as a
+// quality failure.  The joined key is spelt out (flag bits read 'N') and matched as a string: Counter mode through
+// match_key (the byte-string index when the library holds ':' features), Extract+Count through ec_count_key.
+// Returns the reference counter to bump (1..4) with the feature in idx, 0 after an Extract+Count insert, or -1: a
+// pair needs a negative-index slice or the key outgrows the buffer -- the byte-exact routine takes the read.
+// kb: F2Q_PAIRS_KEYMAX bytes of the lane's own (the kernel hands out LDS, 100-byte stride: an odd number of words)
+#define F2Q_PAIRS_KEYMAX 100
+template <int NW, int KB>
+F2Q_HD int pairs_lane(const RunDev &run, const LibDev &lib, const EcDev &ec, uint8_t *kb,
+                      const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW], int r,
+                      const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW],
+                      unsigned long long read_index, uint32_t &idx, uint32_t *n_new)
+{
+    int klen = 0, nparts = 0;
+    for (int i = 0; i < run.n_iter; i++) {
+        const AnchorWin aw = anchor_window_pair<NW, KB, KB>(run, run.up_len[i], run.down_len[i], run.mp_up_pos[i], run.mp_down_pos[i],
+                                                            LO, HI, FLG, r, FU, FD, FW);
+        if (aw.ok == 2) return -1;
+        if (aw.ok != 1) continue;
+        const int L = aw.end - aw.start;
+        if (klen + L + 1 > F2Q_PAIRS_KEYMAX) return -1;
+        if (nparts) kb[klen++] = (uint8_t)':';
+        for (int off = 0; off < L; off += 32) {
+            const int n = L - off < 32 ? L - off : 32;
+            const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
+            const uint32_t fl = plane_extract<NW>(FLG, aw.start + off, n);
+            for (int j = 0; j < n; j++)
+                kb[klen++] = ((fl >> j) & 1u) ? (uint8_t)'N' : (uint8_t)(0x54474341u >> (8u * (((lo >> j) & 1u) | (((hi >> j) & 1u) << 1))));
+        }
+        nparts++;
+    }
+    if (!nparts) return 4;                                               // :389-390
+    KeyView kv; kv.seq = kb; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = klen; kv.len = klen;
+    if (run.mode == 0) return match_key(run, lib, kv, idx);
+    ec_count_key(ec, kv, read_index, n_new);
+    return 0;
+}
 
 // 2-bit interleaved key of window [start, start+L) (L <= 31) from the planes
 template <int NW>
@@ -1648,7 +1771,8 @@ struct PackPlan {
     int from = 0;                  // ... and only [from, need) is ever looked at
     bool inband_n = false;         // non-ACGT symbols travel as flag bits (all-ACGT library only)
     bool n_only = false;           // ... but only the symbol 'N' (Extract+Count: the key spells the symbol, a flag reads 'N')
-    bool fast_anchor = false;      // one --us/--ds pair with ACGT anchors: packed bit-plane path
+    bool fast_anchor = false;      // --us/--ds with ACGT anchors: packed bit-plane path
+    bool multi_pair = false;       // ... several pairs: k_count_anchor_pairs (one search per pair on the same planes)
     int kb = 1;                    // counter bits of the anchor search (0: exact, 1: k <= 1, 3: k <= 7)
 };
 

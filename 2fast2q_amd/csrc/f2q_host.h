@@ -33,7 +33,8 @@ struct HostIndex {
     std::vector<uint16_t> lt_slot_of;
     // general keys (GkDesc): byte-string index of all features by length
     std::vector<GkGroup> gk_groups;
-    std::vector<uint32_t> gk_tab, gk_ids;
+    std::vector<uint32_t> gk_tab, gk_ids, gk_fwoff;
+    std::vector<unsigned long long> gk_fw;
     LenGroup grp[F2Q_REG_MAXLEN + 1];
     uint32_t n_features = 0, n_irregular = 0;
 };
@@ -224,6 +225,20 @@ inline void build_gk(HostIndex &ix, int miss)
         i = j;
     }
     if (ix.gk_groups.empty()) { GkGroup g; memset(&g, 0, sizeof g); g.len = 0xFFFFFFFFu; ix.gk_groups.push_back(g); }
+    // the features once more as zero-padded 8-byte words (GkDesc::fw)
+    ix.gk_fw.clear(); ix.gk_fwoff.assign(ix.n_features + 1, 0u);
+    for (uint32_t f = 0; f < ix.n_features; f++) {
+        const uint32_t len = ix.feat_off[f + 1] - ix.feat_off[f];
+        ix.gk_fwoff[f] = (uint32_t)ix.gk_fw.size();
+        const uint8_t *fb = ix.feat_bytes.data() + ix.feat_off[f];
+        for (uint32_t w = 0; 8 * w < len; w++) {
+            unsigned long long v = 0;
+            for (uint32_t b = 0; b < 8 && 8 * w + b < len; b++) v |= (unsigned long long)fb[8 * w + b] << (8 * b);
+            ix.gk_fw.push_back(v);
+        }
+    }
+    ix.gk_fwoff[ix.n_features] = (uint32_t)ix.gk_fw.size();
+    for (int pad = 0; pad < F2Q_GK_MAXW; pad++) ix.gk_fw.push_back(0ull);     // (the word loop of a short last feature may look past it)
 }
 
 // packed_len: the feature length the packed tables index (the window length of a fixed-offset run); mw_windows >= 2:
@@ -361,6 +376,9 @@ inline PackPlan make_plan(const RunDev &run)
     }
     pl.fast_anchor = !run.fixed && run.n_iter == 1 && run.anchors_packed && run.msu >= 0 && run.msd >= 0 &&
                      run.msu <= 7 && run.msd <= 7 && run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN;
+    // several pairs: every pair searched on the same planes, the parts joined with ':' (fast2q.py:333-363)
+    if (!run.fixed && run.n_iter >= 2 && run.pairs_packed && run.msu >= 0 && run.msd >= 0 && run.msu <= 7 && run.msd <= 7 &&
+        run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN) { pl.fast_anchor = true; pl.multi_pair = true; }
     pl.kb = (run.msu == 0 && run.msd == 0) ? 0 : (run.msu <= 1 && run.msd <= 1) ? 1 : 3;
     // anchored Extract+Count: a read with 'N's keeps to the packed path (an 'N' equals no anchor base; a window that
     // holds one is spelt out from the planes and the flag bits), any other odd symbol sends the read to the byte-exact path
@@ -481,6 +499,19 @@ inline int fill_run(const f2q_params &p, RunDev &r, std::string &err)
             (side ? r.down_pos : r.up_pos)[c] |= 1u << k;
         }
     }
+    // several pairs: the same per-symbol position masks for every pair (all anchors ACGT-only, 1..32 symbols)
+    r.pairs_packed = (r.n_iter >= 2);
+    for (int i = 0; i < r.n_iter && r.pairs_packed; i++)
+        for (int side = 0; side < 2 && r.pairs_packed; side++) {
+            if (!(side ? r.has_down : r.has_up)) continue;
+            const int l = side ? r.down_len[i] : r.up_len[i];
+            if (l < 1 || l > 32) { r.pairs_packed = 0; break; }
+            for (int k = 0; k < l; k++) {
+                const uint32_t c = base_code(side ? r.down[i][k] : r.up[i][k]);
+                if (c > 3u) { r.pairs_packed = 0; break; }
+                (side ? r.mp_down_pos : r.mp_up_pos)[i][c] |= 1u << k;
+            }
+        }
     return F2Q_OK;
 }
 

@@ -209,7 +209,7 @@ static int setup_run(f2q_ctx *c)
     int rc = fill_run(p, c->run_h, err);
     if (rc) return fail(c, rc, err);
     c->plan = make_plan(c->run_h);
-    if (c->force_general) { c->plan.fast_fixed = false; c->plan.fast_anchor = false; }
+    if (c->force_general) { c->plan.fast_fixed = false; c->plan.fast_anchor = false; c->plan.multi_pair = false; }
     return F2Q_OK;
 }
 
@@ -245,6 +245,10 @@ static int upload_lib(f2q_ctx *c)
         if ((rc = dev_upload(c, c->ix.gk_tab.data(), c->ix.gk_tab.size(), &gk_tab, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.gk_ids.data(), c->ix.gk_ids.size(), &gk_ids, c->lib_allocs))) return rc;
         L.gk.n_groups = c->ix.n_features ? (uint32_t)c->ix.gk_groups.size() : 0u; L.gk.grp = gk_grp; L.gk.tab = gk_tab; L.gk.ids = gk_ids;
+        unsigned long long *gk_fw; uint32_t *gk_fwoff;
+        if ((rc = dev_upload(c, c->ix.gk_fw.data(), c->ix.gk_fw.size(), &gk_fw, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.gk_fwoff.data(), c->ix.gk_fwoff.size(), &gk_fwoff, c->lib_allocs))) return rc;
+        L.gk.fw = gk_fw; L.gk.fwoff = gk_fwoff;
     }
     L.tab_keys = tk; L.tab_idx = ti; L.feat_bytes = fb; L.feat_off = fo; L.irr_ids = ir;
     c->guide_keys_d = gk;
@@ -357,7 +361,7 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     HIPC(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < n; i++) if (offs[i + 1] < offs[i]) return fail(c, F2Q_EINVAL, "offsets must be non-decreasing");
     c->plan = make_plan(c->run_h);                   // the library decides below whether the packed paths apply
-    if (c->force_general) { c->plan.fast_fixed = false; c->plan.fast_anchor = false; c->plan.multi = false; }
+    if (c->force_general) { c->plan.fast_fixed = false; c->plan.fast_anchor = false; c->plan.multi = false; c->plan.multi_pair = false; }
     int packed_len = c->plan.fast_fixed ? c->run_h.length : 0;
     if (c->plan.fast_anchor) {
         if (c->run_h.has_up && c->run_h.has_down) {          // variable windows: index the most common feature length
@@ -374,7 +378,7 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     rc = alloc_acc(c, n);
     if (rc) return rc;
     c->plan.inband_n = (c->plan.fast_fixed || c->plan.fast_anchor) && c->ix.n_irregular == 0;
-    if (c->ix.n_irregular) c->plan.fast_anchor = false;      // irregular features need the byte-exact routine
+    if (c->ix.n_irregular && !c->plan.multi_pair) c->plan.fast_anchor = false;      // irregular features need the byte-exact routine (the pair kernel matches strings)
     c->have_lib = true;
     return F2Q_OK;
 }
@@ -543,7 +547,32 @@ static int ec_reserve(f2q_ctx *c, uint64_t keys64, uint64_t reads, uint64_t key_
 // one set of launches over a view of a block (all of it in Counter mode, a step of it in Extract+Count mode)
 static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, Accum &acc, uint32_t &launches)
 {
-    if (pb.n_tiles && pb.planar_nw) {
+    if (pb.n_tiles && pb.planar_nw && c->plan.multi_pair) {
+        // several --us/--ds pairs on the planes
+        const bool lds = c->prm.mode == 0 && c->lib_h.n_features <= F2Q_HIST_MAX;
+        const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * 4u);
+        const size_t shmem = lds ? std::max<size_t>(4, (size_t)c->lib_h.n_features * 4) : 4;
+        const int nw = (int)pb.planar_nw, kb = c->plan.kb;
+        const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
+#define F2Q_LAUNCH_MP2(NW_, KB_, SQ_)                                                                                  \
+        do {                                                                                                           \
+            if (lds) hipLaunchKernelGGL((k_count_anchor_pairs<NW_, KB_, SQ_, true>), dim3(grid), dim3(F2Q_AN_THREADS), shmem, \
+                                        c->stream, c->run_d, c->lib_d, c->ec, pb, acc, c->reads_seen);                 \
+            else hipLaunchKernelGGL((k_count_anchor_pairs<NW_, KB_, SQ_, false>), dim3(grid), dim3(F2Q_AN_THREADS), shmem, \
+                                    c->stream, c->run_d, c->lib_d, c->ec, pb, acc, c->reads_seen);                     \
+        } while (0)
+#define F2Q_LAUNCH_MP(NW_, KB_) do { if (sameq) F2Q_LAUNCH_MP2(NW_, KB_, true); else F2Q_LAUNCH_MP2(NW_, KB_, false); } while (0)
+        if (nw == 3 && kb == 0) F2Q_LAUNCH_MP(3, 0);
+        else if (nw == 3 && kb == 1) F2Q_LAUNCH_MP(3, 1);
+        else if (nw == 3) F2Q_LAUNCH_MP(3, 3);
+        else if (kb == 0) F2Q_LAUNCH_MP(5, 0);
+        else if (kb == 1) F2Q_LAUNCH_MP(5, 1);
+        else F2Q_LAUNCH_MP(5, 3);
+#undef F2Q_LAUNCH_MP
+#undef F2Q_LAUNCH_MP2
+        HIPC(c, hipGetLastError());
+        launches++;
+    } else if (pb.n_tiles && pb.planar_nw) {
         // packed anchored path
         const bool ecm = c->prm.mode == 1;
         const bool lds = !ecm && c->lib_h.n_features <= F2Q_HIST_MAX;
@@ -901,7 +930,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             if (v.index) v.index += (size_t)t0 * F2Q_TILE; else v.first_index += (uint64_t)t0 * F2Q_TILE;
             return v;
         };
-        const bool hot_path = b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot;
+        const bool hot_path = b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot && !c->plan.multi_pair;
         if (hot_path) {
             // anchored tiles: hot keys in LDS.  The first hot_learn reads of a sample go through the same kernel with an
             // empty hot set (every key takes the table's insert); then the set is built and serves the rest of the sample.
@@ -963,8 +992,9 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         } else
         for (uint32_t t0 = 0; t0 < b->pb.n_tiles; t0 += tiles_per) {
             const PackedBlock v = view_of(t0, std::min<uint32_t>(tiles_per, b->pb.n_tiles - t0));
-            // packed reads give single-window keys of at most rmax bytes
-            int rc = ec_reserve(c, v.n_slots, v.n_slots, v.n_slots * ((uint64_t)v.rmax + F2Q_MAX_ITER));
+            // packed reads give single-window keys of at most rmax bytes (several pairs: one window each, at most F2Q_PAIRS_KEYMAX in all)
+            const uint64_t key_max = c->plan.multi_pair ? (uint64_t)F2Q_PAIRS_KEYMAX : (uint64_t)v.rmax + F2Q_MAX_ITER;
+            int rc = ec_reserve(c, v.n_slots, v.n_slots, v.n_slots * key_max);
             if (rc) return rc;
             if ((rc = launch_view(c, v, none, acc, launches))) return rc;
         }
@@ -998,7 +1028,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
         t->fast_reads = b->n_reads - b->n_general; t->launches = launches;
     }
-    if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot)) {
+    if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot && !c->plan.multi_pair)) {
         // (the hot-key path has looked at the counters after its last launch; what its deferred passes could still
         // report is seen by the next call that reads them)
         unsigned long long ctr[4];

@@ -44,6 +44,8 @@ WORKLOADS = {
     "cfg3_2win_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 3, windows=2),
     # config 5: up+guide+down cassette at a uniform offset in [0,100]; --us/--ds anchored search
     "cfg5a_50M_10k_anchor_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True),
+    # two --us/--ds pairs (here: the same cassette twice, so every read gives the key guide:guide) against 10 k two-part features
+    "cfg5c_2pair_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True, pairs=2),
     "cfg5b_50M_anchor_ec": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True, ec=True),
 }
 UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
@@ -94,6 +96,14 @@ def resolve(a, world):
 def make_job(pkg, w, a, device, n, first_read):
     """(context, resident block) of reads [first_read, first_read + n) of the workload's stream"""
     guides = pkg.binding.synth_library(w["lib_seed"], w["n_guides"], 20)
+    if w.get("anchored") and w.get("pairs") == 2:
+        feats = [g + ":" + g for g in guides]
+        c = pkg.Counter(features=feats, miss=w["miss"], phred=a.phred, device=device, upstream=UP + "," + UP, downstream=DOWN + "," + DOWN,
+                        miss_search_up=a.ms, miss_search_down=a.ms)
+        spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n, cassette=True, up=UP,
+                    down=DOWN, max_offset=100)
+        blk = c.synth_create(guides=guides, **spec)
+        return c, blk, feats, spec
     if w.get("anchored"):
         akw = dict(upstream=UP, downstream=DOWN, miss_search_up=a.ms, miss_search_down=a.ms)
         c = pkg.Counter(features=None if w.get("ec") else guides, mode="EC" if w.get("ec") else "C", miss=w["miss"],
@@ -189,7 +199,8 @@ def pmc_traffic(a, dominant):
 def oracle_kwargs(w, a):
     kw = dict(miss=w["miss"], phred=a.phred)
     if w.get("anchored"):
-        kw.update(upstream=UP, downstream=DOWN, miss_search_up=a.ms, miss_search_down=a.ms)
+        rep = w.get("pairs", 1)
+        kw.update(upstream=",".join([UP] * rep), downstream=",".join([DOWN] * rep), miss_search_up=a.ms, miss_search_down=a.ms)
         if w.get("ec"):
             kw["mode"] = "EC"
     elif w.get("windows") == 2:
@@ -315,7 +326,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     name, scaling, w = resolve(a, world)
-    dominant = "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
+    dominant = "k_count_anchor_pairs" if w.get("pairs") else "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
 
     traffic, traffic_detail = None, {"error": "skipped"}
     if world == 1 and not a.no_pmc:

@@ -40,6 +40,7 @@ static void bind_lib(Emu *e)
     L.lt.feat_of = e->ix.lt_feat_of.data();
     L.gk.n_groups = e->ix.n_features ? (uint32_t)e->ix.gk_groups.size() : 0u; L.gk.grp = e->ix.gk_groups.data();
     L.gk.tab = e->ix.gk_tab.data(); L.gk.ids = e->ix.gk_ids.data();
+    L.gk.fw = e->ix.gk_fw.data(); L.gk.fwoff = e->ix.gk_fwoff.data();
     memcpy(L.grp, e->ix.grp, sizeof L.grp);
     e->acc.assign(e->ix.n_features + 5, 0);
 }
@@ -82,7 +83,7 @@ void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t 
     if (e->plan.multi && (!e->ix.mw_ok || e->ix.n_irregular)) { e->plan.multi = false; e->plan.fast_fixed = false; }
     bind_lib(e);
     e->plan.inband_n = (e->plan.fast_fixed || e->plan.fast_anchor) && e->ix.n_irregular == 0;
-    if (e->ix.n_irregular) e->plan.fast_anchor = false;
+    if (e->ix.n_irregular && !e->plan.multi_pair) e->plan.fast_anchor = false;
 }
 
 // the same two-stream split the library does: packed tiles through fixed_lane, the rest through general_read
@@ -120,6 +121,26 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                 FU[cw] = fail_word8(q8, phred_add_hi(e->run.thr_up));
                 FD[cw] = fail_word8(q8, phred_add_hi(e->run.thr_down));
                 FLG[cw] = flagged ? flag_word8(q8) : 0u;
+            }
+            if (e->plan.multi_pair) {
+                // k_count_anchor_pairs: every pair on the same planes, the joined key matched as a string
+                uint32_t idx = 0;
+                uint8_t kb[F2Q_PAIRS_KEYMAX];
+                const int res = pairs_lane<NW, KB>(e->run, e->lib, e->ec, kb, LO, HI, FLG, r, FU, FD, FW, gi, idx, nullptr);
+                if (res < 0) {
+                    uint8_t sq[F2Q_ANCHOR_MAXLEN], ql[F2Q_ANCHOR_MAXLEN];
+                    for (int i = 0; i < r; i++) {
+                        sq[i] = (uint8_t)"ACGT"[((LO[i >> 5] >> (i & 31)) & 1u) | (((HI[i >> 5] >> (i & 31)) & 1u) << 1)];
+                        ql[i] = (uint8_t)((Q[planar_qword((uint32_t)i)] >> (8 * planar_qbyte((uint32_t)i))) & 0xFFu);
+                        if (ql[i] & 0x80u) { sq[i] = (uint8_t)'N'; ql[i] &= 0x7Fu; }
+                    }
+                    general_read<const uint8_t *>(e->run, e->lib, e->ec, acc, sq, r, ql, r, gi, acc.stats);
+                    return;
+                }
+                acc.stats[0]++;
+                if (res == 0) acc.stats[1]++;
+                else { acc.stats[res]++; if (res == 1 || res == 2) acc.counts[idx]++; }
+                return;
             }
             const AnchorWin aw = anchor_window<NW, KB, KB>(e->run, LO, HI, FLG, r, FU, FD, FW);
             const int L = aw.end - aw.start;

@@ -585,6 +585,29 @@ def test_general_key_index_kernel_vs_oracle(P, miss, glen):
     assert stats[1] > 0 and (miss == 0 or stats[2] > 0)
 
 
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("ms,three", [(0, False), (1, False), (1, True)])
+def test_multi_pair_packed_kernel_vs_oracle(P, monkeypatch, mode, ms, three):
+    """k_count_anchor_pairs (several --us/--ds pairs on the planes, joined keys matched as strings) against the oracle
+    and against the byte-exact general kernel"""
+    from test_lane_logic_cpu import multi_pair_case
+    lib, fq, ups, downs = multi_pair_case(30000, 21 + ms + (10 if three else 0), n_guides=400, three=three)
+    kw = dict(mode=mode, miss=1, upstream=",".join(ups), downstream=",".join(downs), miss_search_up=ms, miss_search_down=ms)
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)] if mode == "C" else None, **kw)
+    o.count_fastq(fq)
+    res = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("F2Q_FORCE_GENERAL", env)
+        with P.Counter(features=lib if mode == "C" else None, **kw) as c:
+            _, t = c.count_block(fq, want_timing=True)
+            counts, stats = c.read_counts()
+            assert (t["fast_reads"] > 0.8 * t["reads"]) if env == "0" else (t["fast_reads"] == 0)
+            res.append((list(stats), list(counts) if mode == "C" else [(k, n) for k, n, _ in c.ec_results()]))
+    monkeypatch.delenv("F2Q_FORCE_GENERAL")
+    assert res[0] == res[1] and res[0][0] == o.stats()
+    assert res[0][1] == (o.counts() if mode == "C" else list(zip(o.keys(), o.counts())))
+
+
 def test_two_window_full_size(P, monkeypatch):
     """50M reads, two 10-base windows (--st 0,10 --l 10) against 10k two-part features: the packed multi-window kernel
     against the single-window run of the 20-base form of the same library on the same reads (same counts: see below),

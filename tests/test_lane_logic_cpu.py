@@ -250,6 +250,58 @@ def test_general_key_index_vs_oracle(miss, glen):
 UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
 
 
+UP2, DOWN2 = "ACCTGGATCCAA", "TTCAGGCATGCA"
+
+
+def multi_pair_case(n_reads, seed, n_guides=120, three=False):
+    """reads that carry two (three) cassettes UPi + guide + DOWNi; substitutions, low qualities, an occasional N, some
+    cassettes destroyed so that parts drop out; the library joins the planted guides with ':' and also holds plain ones"""
+    import random
+    rng = random.Random(seed)
+    guides = synth.make_library(n_guides, 18, 300 + seed)
+    ups, downs = [UP, UP2] + (["GGTACCTTAGCA"] if three else []), [DOWN, DOWN2] + (["CATGTTGACCTA"] if three else [])
+    lib = [":".join(guides[(i * (k + 3) + k) % n_guides] for k in range(len(ups))) for i in range(n_guides)]
+    lib += guides[:20]                                                 # one-part features: reads whose other part failed
+    recs = []
+    for i in range(n_reads):
+        g = rng.randrange(n_guides)
+        parts = [guides[(g * (k + 3) + k) % n_guides] for k in range(len(ups))]
+        seq = "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 9)))
+        for k in range(len(ups)):
+            seq += ups[k] + parts[k] + downs[k] + "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 6)))
+        b = bytearray(seq.encode())
+        q = bytearray(b"I" * len(b))
+        for _ in range(rng.choice([0, 0, 0, 1, 1, 2, 4])):
+            b[rng.randrange(len(b))] = rng.choice(b"ACGT")
+        if rng.random() < 0.05:
+            b[rng.randrange(len(b))] = ord("N")
+        if rng.random() < 0.2:
+            q[rng.randrange(len(q))] = rng.choice(b"#+5:")
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, bytes(b), bytes(q)))
+    return lib, b"".join(recs), ups, downs
+
+
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("ms,three", [(0, False), (1, False), (1, True), (2, False)])
+def test_multi_pair_packed_logic_vs_oracle(mode, ms, three):
+    """several --us/--ds pairs on the planes (pairs_lane): every pair searched on its own, parts joined with ':', failed
+    parts left out -- against the oracle, Counter mode (string match against ':' features, m = 1) and Extract+Count"""
+    lib, fq, ups, downs = multi_pair_case(2500, 7 + ms + (10 if three else 0), three=three)
+    kw = dict(mode=mode, miss=1, upstream=",".join(ups), downstream=",".join(downs), miss_search_up=ms, miss_search_down=ms)
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)] if mode == "C" else None, **kw)
+    o.count_fastq(fq)
+    e = Emu(features=lib if mode == "C" else None, **kw)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats()
+    assert e.anchor_reads() == fast and fast > 0.8 * stats[0]            # the packed path did the work
+    if mode == "C":
+        assert counts == o.counts() and stats[1] > 0 and stats[2] > 0
+    else:
+        assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
+        assert any(":" in k for k in o.keys())
+
+
 @pytest.mark.parametrize("mode", ["C", "EC"])
 @pytest.mark.parametrize("anchors", ["both", "up", "down"])
 @pytest.mark.parametrize("ms,qs", [(0, 30), (1, 30), (2, 30), (1, 12), (3, 41)])
