@@ -1660,9 +1660,9 @@ __global__ __launch_bounds__(F2Q_GEN_THREADS) void k_count_general(const RunDev 
             stage_line(mine + F2Q_GEN_WORDS, raw, qo, qn);
             const uint8_t *sl = reinterpret_cast<const uint8_t *>(mine) + ms;
             const uint8_t *ql = reinterpret_cast<const uint8_t *>(mine + F2Q_GEN_WORDS) + mq;
-            general_read<const uint8_t *>(run, lib, ec, acc, sl, r, ql, qn, gi, st, &n_new);
+            general_read<const uint8_t *, true>(run, lib, ec, acc, sl, r, ql, qn, gi, st, &n_new);
         } else {
-            general_read(run, lib, ec, acc, raw + so, r, raw + qo, qn, gi, st, &n_new);
+            general_read<gbytes, true>(run, lib, ec, acc, raw + so, r, raw + qo, qn, gi, st, &n_new);
         }
     }
     if (run.mode == 1) ec64_report_new(ec, n_new);

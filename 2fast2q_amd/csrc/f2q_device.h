@@ -486,19 +486,21 @@ F2Q_HD bool gk_range_clear(unsigned long long lo, unsigned long long hi, int a, 
     return true;
 }
 // exact hit among the features of the group: feature index or -1
-template <class KV>
+// WORDS: check candidates on 8-byte words (13 more live registers: only where the byte-string index is the main road --
+// the general kernel, the pair kernel; the packed kernels reach it for a stray read and keep the byte loop)
+template <bool WORDS, class KV>
 F2Q_HD int gk_exact(const LibDev &lib, const GkGroup &g, const KV &kv)
 {
     const uint32_t m = (1u << g.bits) - 1u;
     uint32_t s = (uint32_t)(gk_hash_key(kv, 0, kv.len, 0xE0u) >> (64u - g.bits));
     const auto tab = gp(lib.gk.tab);
-    const bool words = kv.len <= 8 * F2Q_GK_MAXW && lib.gk.fw != nullptr;
+    const bool words = WORDS && kv.len <= 8 * F2Q_GK_MAXW && lib.gk.fw != nullptr;
     GkKey k;
-    if (words) gk_key_words(kv, k);
+    if (WORDS && words) gk_key_words(kv, k);
     for (;;) {
         const uint32_t e = tab[g.exact_off + s];
         if (e == 0u) return -1;
-        if (words) {
+        if (WORDS && words) {
             unsigned long long lo, hi;
             gk_diff_bytes(lib, k, e - 1u, kv.len, lo, hi);
             if ((lo | hi) == 0ull) return (int)(e - 1u);
@@ -507,21 +509,21 @@ F2Q_HD int gk_exact(const LibDev &lib, const GkGroup &g, const KV &kv)
     }
 }
 // pigeonhole search over the group (see lib_near): every feature within t.best of the key agrees with it on a whole piece
-template <class KV>
+template <bool WORDS, class KV>
 F2Q_HD void gk_near(const LibDev &lib, const GkGroup &g, const KV &kv, MinTrack &t)
 {
     const uint32_t m = (1u << g.bits) - 1u;
     const auto tab = gp(lib.gk.tab);
-    const bool words = kv.len <= 8 * F2Q_GK_MAXW && lib.gk.fw != nullptr;
+    const bool words = WORDS && kv.len <= 8 * F2Q_GK_MAXW && lib.gk.fw != nullptr;
     GkKey k;
-    if (words) gk_key_words(kv, k);
+    if (WORDS && words) gk_key_words(kv, k);
     for (uint32_t p = 0; p < g.n_pieces; p++) {
         const int a = (int)g.cut[p], b = (int)g.cut[p + 1];
         uint32_t s = (uint32_t)(gk_hash_key(kv, a, b, p) >> (64u - g.bits));
         for (;;) {
             const uint32_t e = tab[g.piece_off[p] + s];
             if (e == 0u) break;
-            if (words) {
+            if (WORDS && words) {
                 unsigned long long lo, hi;
                 gk_diff_bytes(lib, k, e - 1u, kv.len, lo, hi);
                 if (gk_range_clear(lo, hi, a, b)) {
@@ -545,7 +547,7 @@ F2Q_HD void gk_near(const LibDev &lib, const GkGroup &g, const KV &kv, MinTrack 
 
 // Counter-mode decision for one extracted key: returns 1 perfect, 2 imperfect, 3 non-aligned,
 // and the feature index in `idx`.
-template <class KV>
+template <bool WORDS = false, class KV>
 F2Q_HD int match_key(const RunDev &run, const LibDev &lib, const KV &kv, uint32_t &idx)
 {
     // is the key a plain ACGT string short enough for the 2-bit index?
@@ -572,10 +574,10 @@ F2Q_HD int match_key(const RunDev &run, const LibDev &lib, const KV &kv, uint32_
         // index over ALL features of the key's length (the reference compares with every same-length feature, :683)
         const GkGroup *g = gk_find(lib, kv.len);
         if (g) {
-            const int e = gk_exact(lib, *g, kv);
+            const int e = gk_exact<WORDS>(lib, *g, kv);
             if (e >= 0) { idx = (uint32_t)e; return 1; }
             if (run.miss > 0) {
-                if (g->n_pieces) gk_near(lib, *g, kv, t);
+                if (g->n_pieces) gk_near<WORDS>(lib, *g, kv, t);
                 else lib_scan(lib, kv, lib.gk.ids + g->ids_off, g->n, t);   // fewer bytes than pieces: the whole group is within reach
             }
         }
@@ -867,7 +869,8 @@ F2Q_HD void ec_count_key(const EcDev &ec, const KV &kv, unsigned long long read_
 // ---------------------------------------------------------------------------------------------
 // general path: one read given as raw bytes.  st[] = the 5 reference counters (thread-local).
 // ---------------------------------------------------------------------------------------------
-template <class P>
+// WORDS: see gk_exact (true where this routine is the main road: k_count_general, the host twin)
+template <class P, bool WORDS = false>
 F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, const Accum &acc,
                          P seq, int r, P qual, int qn,
                          unsigned long long read_index, unsigned long long st[5], uint32_t *n_new = nullptr)
@@ -892,7 +895,7 @@ F2Q_HD void general_read(const RunDev &run, const LibDev &lib, const EcDev &ec, 
     if (kv.nseg > 0) {
         if (run.mode == 0) {
             uint32_t idx = 0;
-            int res = match_key(run, lib, kv, idx);
+            int res = match_key<WORDS>(run, lib, kv, idx);
             if (res == 1 || res == 2) acc_add(&acc.counts[idx], 1ull);
             st[res]++;
         } else {
@@ -1745,7 +1748,7 @@ F2Q_HD int pairs_lane(const RunDev &run, const LibDev &lib, const EcDev &ec, uin
     }
     if (!nparts) return 4;                                               // :389-390
     KeyView kv; kv.seq = kb; kv.nseg = 1; kv.a[0] = 0; kv.b[0] = klen; kv.len = klen;
-    if (run.mode == 0) return match_key(run, lib, kv, idx);
+    if (run.mode == 0) return match_key<true>(run, lib, kv, idx);
     ec_count_key(ec, kv, read_index, n_new);
     return 0;
 }

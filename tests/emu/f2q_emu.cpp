@@ -408,7 +408,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
     }
     for (size_t g = 0; g < hp.g_len.size(); g++) {
         const uint8_t *seq = hp.raw.data() + hp.g_off[g];
-        general_read(e->run, e->lib, e->ec, acc, seq, (int)hp.g_len[g], seq + hp.g_len[g], (int)hp.g_qlen[g],
+        general_read<const uint8_t *, true>(e->run, e->lib, e->ec, acc, seq, (int)hp.g_len[g], seq + hp.g_len[g], (int)hp.g_qlen[g],
                      e->reads_seen + hp.g_index[g], acc.stats);
     }
     e->reads_seen += recs.size(); e->fast += hp.n_clean; e->general += hp.g_len.size();
