@@ -89,3 +89,29 @@ grep -h "Sample bz was processed" $O/bz_one.log $O/bz_rank0.log $O/bz_rank1.log 
 A=$(find $W/zone -name "one.csv" | head -1); B=$(find $W/ztwo -name "two.csv" | head -1)
 if [ -n "$A" ] && [ -n "$B" ] && cmp $A $B; then echo "BGZF file: compiled tables identical ($(wc -l < $A) rows), each rank inflated only its own runs of members" | tee -a $O/progress.txt; else echo "BGZF file: tables differ or missing [$A] [$B]" | tee -a $O/progress.txt; tail -20 $O/bz_rank0.log; fi
 true
+# Extract+Count (--mo EC --us/--ds) as two ranks: the ranks' key tables are merged by key (counts summed, first read = min),
+# the compiled table must equal the single-process one; the BGZF file of cassette reads goes by runs of members
+python - "$W" <<'PY'
+import sys, os, importlib
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+from conftest import bgzf_bytes
+pkg = importlib.import_module("2fast2q_amd")
+w = sys.argv[1]
+os.makedirs(w + "/ec")
+guides = [l.split(",")[1].strip() for l in open(w + "/g.csv")]
+UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+with pkg.Counter(features=guides, miss=1) as c:
+    fq = bytes(c.synth_fastq(seed=8, n_reads=1_200_000, read_len=150, cassette=True, up=UP, down=DOWN, max_offset=100))
+open(w + "/ec/ecp.fastq", "wb").write(fq[: len(fq) // 2][: fq[: len(fq) // 2].rfind(b"\n@") + 1])
+open(w + "/ec/ecz.fastq.gz", "wb").write(bgzf_bytes(fq[len(fq) // 2:][fq[len(fq) // 2:].find(b"\n@") + 1:], level=1))
+PY
+export F2Q_PIECE_BYTES=16777216 F2Q_HOT_LEARN=65536
+timeout -s ABRT -k 5 200 python -m 2fast2q_amd -c --s $W/ec --o $W/eone --fn one --mo EC --us GTTTAAGAGCTA --ds CGTTACCAGGTT --msu 1 --msd 1 --pb > $O/ec_one.log 2>&1
+for r in 0 1; do
+  RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29524 F2Q_DEVICE=0 F2Q_DIST_BACKEND=gloo \
+    timeout -s ABRT -k 5 200 python -m 2fast2q_amd -c --s $W/ec --o $W/etwo --fn two --mo EC --us GTTTAAGAGCTA --ds CGTTACCAGGTT --msu 1 --msd 1 --pb > $O/ec_rank$r.log 2>&1 &
+done
+wait
+A=$(find $W/eone -name "one.csv" | head -1); B=$(find $W/etwo -name "two.csv" | head -1)
+if [ -n "$A" ] && [ -n "$B" ] && cmp $A $B; then echo "Extract+Count: compiled tables identical ($(wc -l < $A) rows: keys in first-seen order), plain file by pieces + BGZF file by runs of members, hot keys in LDS on both ranks" | tee -a $O/progress.txt; else echo "Extract+Count: tables differ or missing [$A] [$B]" | tee -a $O/progress.txt; tail -20 $O/ec_rank0.log; tail -5 $O/ec_one.log; fi
+true
