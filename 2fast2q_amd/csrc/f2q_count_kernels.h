@@ -989,7 +989,8 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor_pairs(const Run
     const RunDev &run = *runp;
     const LibDev &lib = *libp;
     const uint32_t nf = lib.n_features, tid = threadIdx.x;
-    if (USE_LDS) for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) pairs_hist[i] = 0;
+    // the histogram: two u16 counters per word, a counter that reaches 0x8000 hands 0x8000 counts to the global vector
+    if (USE_LDS) for (uint32_t i = tid; i < (nf + 1u) / 2u; i += F2Q_AN_THREADS) pairs_hist[i] = 0;
     __syncthreads();
     const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
     unsigned long long st[5] = {0, 0, 0, 0, 0};
@@ -1031,7 +1032,13 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor_pairs(const Run
         if (res == 0) st[1]++;                                   // Extract+Count: the key went into a table (:387)
         else {
             st[res]++;
-            if (res == 1 || res == 2) { if (USE_LDS) atomicAdd(&pairs_hist[idx], 1u); else acc_add(&acc.counts[idx], 1ull); }
+            if (res == 1 || res == 2) {
+                if (USE_LDS) {
+                    const uint32_t sh = (idx & 1u) << 4;
+                    const uint32_t old = atomicAdd(&pairs_hist[idx >> 1], 1u << sh);
+                    if (((old >> sh) & 0xFFFFu) == 0x7FFFu) { atomicSub(&pairs_hist[idx >> 1], 0x8000u << sh); acc_add(&acc.counts[idx], 0x8000ull); }
+                } else acc_add(&acc.counts[idx], 1ull);
+            }
         }
     }
     if (run.mode == 1) ec64_report_new(ec, n_new);
@@ -1039,7 +1046,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor_pairs(const Run
     flush_stats(acc, st, st_lds, nullptr);
     if (USE_LDS) {
         __syncthreads();
-        for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) { const uint32_t n = pairs_hist[i]; if (n) acc_add(&acc.counts[i], (unsigned long long)n); }
+        for (uint32_t i = tid; i < nf; i += F2Q_AN_THREADS) { const uint32_t n = (pairs_hist[i >> 1] >> ((i & 1u) << 4)) & 0xFFFFu; if (n) acc_add(&acc.counts[i], (unsigned long long)n); }
     }
 }
 

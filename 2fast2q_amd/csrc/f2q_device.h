@@ -1720,8 +1720,9 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
 // match_key (the byte-string index when the library holds ':' features), Extract+Count through ec_count_key.
 // Returns the reference counter to bump (1..4) with the feature in idx, 0 after an Extract+Count insert, or -1: a
 // pair needs a negative-index slice or the key outgrows the buffer -- the byte-exact routine takes the read.
-// kb: F2Q_PAIRS_KEYMAX bytes of the lane's own (the kernel hands out LDS, 100-byte stride: an odd number of words)
-#define F2Q_PAIRS_KEYMAX 100
+// kb: F2Q_PAIRS_KEYMAX bytes of the lane's own (the kernel hands out LDS, 68-byte stride: an odd number of words; two
+// parts of 31 bases and their ':' fit, a longer key takes the byte-exact routine)
+#define F2Q_PAIRS_KEYMAX 68
 template <int NW, int KB>
 F2Q_HD int pairs_lane(const RunDev &run, const LibDev &lib, const EcDev &ec, uint8_t *kb,
                       const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW], int r,
