@@ -1,0 +1,5 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export F2Q_LIB_PATH=$GRAFT_REPO_ROOT/2fast2q_amd/lib/libf2q_hip_stamp.so
+for w in cfg4_50M_100k_m1; do
+  timeout -k 10 300 python bench.py --workload $w --steps 3 --warmup 1 --no-pmc --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep stamp | tail -2
+done
