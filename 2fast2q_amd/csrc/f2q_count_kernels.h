@@ -1512,6 +1512,170 @@ __global__ __launch_bounds__(256) void k_ec_deferred_slow(const RunDev *__restri
     flush_stats(acc, st, st_lds, nullptr);
 }
 
+// ---- Extract+Count with a fixed window and the hot keys in LDS ---------------------------------------------------------
+// k_extract_fixed4's tile walk (one wave per tile, 4 reads per lane) in front of k_extract_anchor_hot's counting stage:
+// amplicon-like samples repeat a few thousand windows, and those are counted in LDS instead of one device-scope atomic
+// per read.  A fixed window of <= 29 bases always has a single-word form and the packer passes no flagged read, so the
+// only reads set aside are those that meet a full table (k_ec_deferred_fixed inserts them after the table has grown).
+#define F2Q_FH_THREADS 1024
+#define F2Q_FH_WAVES (F2Q_FH_THREADS / 64)
+template <bool LEARN>
+__global__ __launch_bounds__(F2Q_FH_THREADS) void k_extract_fixed4_hot(const RunDev *__restrict__ runp, EcDev ec, EcHot hot, PackedBlock pb,
+                                                                       Accum acc, uint64_t read_base,
+                                                                       unsigned long long *__restrict__ defer, uint64_t slot_base, uint64_t defer_cap)
+{
+    extern __shared__ uint32_t hot_smem[];
+    uint32_t *tg = hot_smem, *cnt = hot_smem + F2Q_HOT_SLOTS;
+    const RunDev &run = *runp;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(hot.tags);
+        v4 *dst = reinterpret_cast<v4 *>(tg);
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 4u; i += F2Q_FH_THREADS) dst[i] = src[i];
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_FH_THREADS) cnt[i] = 0;
+    }
+    __syncthreads();
+    const FixedGeom g = fixed_geom(run);
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 F2Q_GLOBAL *kf = (const v2u64 F2Q_GLOBAL *)gp(hot.kf);
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    uint32_t n_new = 0;
+    for (uint32_t base = blockIdx.x * F2Q_FH_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_FH_WAVES) {
+        const uint32_t tile = base + wave;
+        if (tile >= pb.n_tiles) continue;
+        U4 brow[F2Q_MAXBROWS], qrow[F2Q_MAXQROWS];
+        const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane;
+        const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane;
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXBROWS; r++) {
+            uint32_t row = (uint32_t)g.bw0 + (uint32_t)(r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
+            row = row < pb.wb ? row : pb.wb - 1u;
+            brow[r] = ld_u4<true>(bp + (uint64_t)row * F2Q_TILE);
+        }
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXQROWS; r++) {
+            const uint32_t want = (uint32_t)g.qw0 + (uint32_t)(r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
+            const uint32_t row = want < pb.wq ? want : pb.wq - 1u;
+            qrow[r] = (g.add_hi && want < pb.wq) ? ld_u4<true>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
+        }
+        uint32_t len01 = 0, len23 = 0;
+        if (pb.len) {
+            typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+            v2 lv = *(const v2 F2Q_GLOBAL *)(gp(pb.len) + (uint64_t)tile * F2Q_TILE + 4u * lane);
+            len01 = lv.x; len23 = lv.y;
+        }
+        uint32_t bad[4] = {0, 0, 0, 0};
+        if (g.add_hi) {
+#pragma unroll
+            for (int r = 0; r < F2Q_MAXQROWS; r++)
+                if (r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
+        }
+        // the four reads' tag buckets are read together, then verified and counted one after the other
+        unsigned long long k[4]; bool ins[4]; HotProbe q[4]; U4 t1[4], t2[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
+            const bool live = l != F2Q_LEN_SKIP;
+            ins[j] = live && !bad[j];
+            st[0] += live; st[4] += live && bad[j];
+            const int rl = (int)(l & 0x7FFFu);
+            int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;             // Python slice clipping (:354)
+            if (L < 0) L = 0;
+            const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
+            k[j] = ((unsigned long long)L << 58) | key;
+            q[j] = hot_probe(k[j]);
+            t1[j] = lds_u4(tg + 4u * q[j].b1); t2[j] = lds_u4(tg + 4u * q[j].b2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t slot = (uint64_t)tile * F2Q_TILE + 4u * lane + (uint32_t)j;
+            const uint32_t c1 = hot_match(t1[j], q[j].tag, q[j].b1), c2 = hot_match(t2[j], q[j].tag, q[j].b2);
+            uint32_t s = c1 != F2Q_HOT_NONE ? c1 : c2;
+            bool hit = false, full = false;
+            unsigned long long gi = 0;
+            if (ins[j]) {
+                gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+                if (s != F2Q_HOT_NONE) {
+                    v2u64 e = kf[s];
+                    hit = e.x == k[j] && gi >= e.y;
+                    if (!hit && c1 != F2Q_HOT_NONE && c2 != F2Q_HOT_NONE) { s = c2; e = kf[s]; hit = e.x == k[j] && gi >= e.y; }
+                }
+            }
+            if (hit) { atomicAdd(&cnt[s], 1u); st[1]++; }
+            else if (ins[j]) {
+                uint32_t ts = 0; unsigned long long before = 0;
+                const uint32_t rr = ec64_try_insert<LEARN>(ec, k[j], gi, F2Q_HOT_MAXPROBE, ts, before);
+                full = rr == 2u;
+                n_new += rr & 1u;
+                st[1] += !full;
+                if (LEARN && rr != 2u && before + 1ull == F2Q_HOT_MINCOUNT) {
+                    const unsigned long long at = ec_fetch_add(ec.ctr + F2Q_CTR_CAND, 1ull);
+                    if (at < F2Q_HOT_CAND) gpw(hot.cand)[at] = ts;
+                }
+            }
+            const unsigned long long fm = __ballot(full);
+            if (fm) {                                           // the table is (nearly) full: inserted after it has grown
+                unsigned long long at = 0;
+                const int first = __builtin_ctzll(fm);
+                if (lane == (uint32_t)first) at = ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE, (unsigned long long)__popcll(fm));
+                at = __shfl(at, first, 64);
+                const unsigned long long di = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                if (full && di < defer_cap) gpw(defer)[di] = defer_entry(slot_base + slot, true, 0, 0);
+                else if (full) F2Q_ST64(&ec.ctr[2], 7ull);
+                if (lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(fm));
+            }
+        }
+    }
+    ec64_report_new(ec, n_new);
+    __syncthreads();
+    for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_FH_THREADS) {
+        const uint32_t n = cnt[i];
+        if (n) {
+            const uint32_t ts = gp(hot.slot)[i];
+            if (ts <= ec.k64_mask) ec_add(&ec.k64_count[ts], (unsigned long long)n);
+            else F2Q_ST64(&ec.ctr[2], 8ull);
+        }
+    }
+    __syncthreads();
+    flush_stats(acc, st, reinterpret_cast<unsigned long long *>(hot_smem), nullptr);
+}
+
+// the reads k_extract_fixed4_hot set aside (they met a full table): the window again from the tile, plain insert
+__global__ __launch_bounds__(256) void k_ec_deferred_fixed(const RunDev *__restrict__ runp, EcDev ec, PackedBlock pb, Accum acc, uint64_t read_base,
+                                                           const unsigned long long *__restrict__ defer)
+{
+    const RunDev &run = *runp;
+    const FixedGeom g = fixed_geom(run);
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    uint32_t n_new = 0;
+    unsigned long long n = ec.ctr[F2Q_CTR_ASIDE];
+    if (n > pb.n_slots) n = pb.n_slots;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+        const uint64_t slot = gp(defer)[i] >> 32;
+        if (slot >= pb.n_slots) continue;
+        const uint32_t tile = (uint32_t)(slot / F2Q_TILE), in_tile = (uint32_t)(slot % F2Q_TILE), lane4 = in_tile >> 2, j = in_tile & 3u;
+        U4 brow[F2Q_MAXBROWS];
+        const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane4;
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXBROWS; r++) {
+            uint32_t row = (uint32_t)g.bw0 + (uint32_t)(r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
+            row = row < pb.wb ? row : pb.wb - 1u;
+            brow[r] = ld_u4<false>(bp + (uint64_t)row * F2Q_TILE);
+        }
+        const uint32_t l = pb.len ? gp(pb.len)[slot] : pb.rmax;
+        const int rl = (int)(l & 0x7FFFu);
+        int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;
+        if (L < 0) L = 0;
+        const uint64_t key = fixed4_key(g, brow, (int)j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
+        n_new += ec64_insert_n(ec, key, L, read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
+        st[1]++;
+    }
+    ec64_report_new(ec, n_new);
+    __shared__ unsigned long long st_lds[8];
+    flush_stats(acc, st, st_lds, nullptr);
+}
+
 // hot-key set of the single-word table: built from the candidates the learning launches noted (in the order they
 // reached F2Q_HOT_MINCOUNT reads, the first F2Q_HOT_CAP of them), re-linked after the table has grown
 __global__ __launch_bounds__(256) void k_ec_hot_build(EcDev ec, EcHot hot)

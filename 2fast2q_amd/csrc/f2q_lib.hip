@@ -846,9 +846,18 @@ static int launch_hot(f2q_ctx *c, const PackedBlock &v, uint64_t slot_base, Accu
     if (learning) HIPC(c, hipMemsetAsync(c->hot.tags, 0, (size_t)F2Q_HOT_SLOTS * 4, c->stream));   // an empty set
     const int nw = (int)v.planar_nw, kb = c->plan.kb;
     const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
+    const size_t shmem = (size_t)F2Q_HOT_SLOTS * 8;
+    if (!v.planar_nw) {
+        // fixed window: one wave per tile
+        const uint32_t wgs = (v.n_tiles + F2Q_FH_WAVES - 1) / F2Q_FH_WAVES;
+        const uint32_t fgrid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu);
+        auto kern = learning ? k_extract_fixed4_hot<true> : k_extract_fixed4_hot<false>;
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(F2Q_FH_THREADS), shmem, c->stream, c->run_d, c->ec, c->hot, v, acc, c->reads_seen,
+                           c->defer_d, slot_base, (uint64_t)c->defer_cap);
+    } else {
     const uint32_t groups = (v.n_tiles + F2Q_HOT_GROUPS - 1) / F2Q_HOT_GROUPS;
     const uint32_t grid = std::min<uint32_t>(groups, (uint32_t)c->n_cu);
-    const size_t shmem = (size_t)F2Q_HOT_SLOTS * 8;
 #define F2Q_LAUNCH_HOT2(NW_, KB_, SQ_)                                                                                 \
     do {                                                                                                               \
         auto kern = learning ? k_extract_anchor_hot<NW_, KB_, SQ_, true> : k_extract_anchor_hot<NW_, KB_, SQ_, false>; \
@@ -865,6 +874,7 @@ static int launch_hot(f2q_ctx *c, const PackedBlock &v, uint64_t slot_base, Accu
     else F2Q_LAUNCH_HOT(5, 3);
 #undef F2Q_LAUNCH_HOT
 #undef F2Q_LAUNCH_HOT2
+    }
     HIPC(c, hipGetLastError());
     launches++;
     if (aux_block && (rc = launch_aux_general(c, aux_block, acc, launches))) return rc;
@@ -890,7 +900,12 @@ static int hot_aside(f2q_ctx *c, const PackedBlock &blk, Accum &acc, uint32_t &l
         launches++;
         EC_POINT(c, "k_ec_deferred_keys");
     }
-    if (n_slow) {
+    if (n_slow && !blk.planar_nw) {
+        hipLaunchKernelGGL(k_ec_deferred_fixed, dim3(g), dim3(256), 0, c->stream, c->run_d, c->ec, blk, acc, c->reads_seen, c->defer_d);
+        HIPC(c, hipGetLastError());
+        launches++;
+        EC_POINT(c, "k_ec_deferred_fixed");
+    } else if (n_slow) {
         hipLaunchKernelGGL(k_ec_deferred_slow, dim3(g), dim3(256), 0, c->stream, c->run_d, c->lib_d, c->ec, blk, acc, c->reads_seen, c->defer_d);
         HIPC(c, hipGetLastError());
         launches++;
@@ -930,7 +945,8 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             if (v.index) v.index += (size_t)t0 * F2Q_TILE; else v.first_index += (uint64_t)t0 * F2Q_TILE;
             return v;
         };
-        const bool hot_path = b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot && !c->plan.multi_pair;
+        // anchored tiles (one pair) and fixed-window tiles take the hot-key kernels
+        const bool hot_path = b->pb.n_tiles && !c->no_hot && !c->plan.multi_pair && (b->pb.planar_nw ? b->pb.len != nullptr : true);
         if (hot_path) {
             // anchored tiles: hot keys in LDS.  The first hot_learn reads of a sample go through the same kernel with an
             // empty hot set (every key takes the table's insert); then the set is built and serves the rest of the sample.
@@ -1028,7 +1044,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
         t->fast_reads = b->n_reads - b->n_general; t->launches = launches;
     }
-    if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && b->pb.planar_nw && b->pb.len && !c->no_hot && !c->plan.multi_pair)) {
+    if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && !c->no_hot && !c->plan.multi_pair && (b->pb.planar_nw ? b->pb.len != nullptr : true))) {
         // (the hot-key path has looked at the counters after its last launch; what its deferred passes could still
         // report is seen by the next call that reads them)
         unsigned long long ctr[4];

@@ -46,6 +46,8 @@ WORKLOADS = {
     "cfg5a_50M_10k_anchor_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True),
     # two --us/--ds pairs (here: the same cassette twice, so every read gives the key guide:guide) against 10 k two-part features
     "cfg5c_2pair_50M_10k_m1": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True, pairs=2),
+    # Extract+Count with a fixed window on the config-3 reads
+    "cfg3b_50M_fixed_ec": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 3, ec=True),
     "cfg5b_50M_anchor_ec": dict(n_reads=50_000_000, n_guides=10000, miss=1, lib_seed=0xF2A5 + 5, anchored=True, ec=True),
 }
 UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
@@ -117,6 +119,10 @@ def make_job(pkg, w, a, device, n, first_read):
         spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n)
         blk = c.synth_create(guides=guides, **spec)
         return c, blk, feats, spec
+    elif w.get("ec"):
+        c = pkg.Counter(features=None, mode="EC", phred=a.phred, length=20, start="0", device=device)
+        spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n)
+        blk = c.synth_create(guides=guides, **spec)
     else:
         c = pkg.Counter(features=guides, miss=w["miss"], phred=a.phred, length=20, start="0", device=device)
         spec = dict(seed=SEED, n_reads=n, first_read=first_read, read_len=a.read_len, p_n=a.p_n)
@@ -207,6 +213,8 @@ def oracle_kwargs(w, a):
         kw.update(length=10, start="0,10")
     else:
         kw.update(length=20, start="0")
+        if w.get("ec"):
+            kw["mode"] = "EC"
     return kw
 
 
@@ -332,7 +340,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     name, scaling, w = resolve(a, world)
-    dominant = "k_count_anchor_pairs" if w.get("pairs") else "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
+    dominant = "k_extract_fixed4" if w.get("ec") and not w.get("anchored") else "k_count_anchor_pairs" if w.get("pairs") else "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
 
     traffic, traffic_detail = None, {"error": "skipped"}
     if world == 1 and not a.no_pmc:

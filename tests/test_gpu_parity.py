@@ -311,6 +311,32 @@ def test_ec_hot_keys_vs_oracle(P, monkeypatch, learn, anchors):
     assert max(n for _, n, _ in res[0][1]) > 100                  # there were hot keys
 
 
+@pytest.mark.parametrize("learn,start,length,rl", [("256", 10, 20, 80), ("5000", 0, 29, 40), ("256", 3, 12, 14), ("1000000", 10, 20, 80)])
+def test_ec_hot_keys_fixed_window(P, monkeypatch, learn, start, length, rl):
+    """Extract+Count with a fixed window and the hot keys in LDS (k_extract_fixed4_hot) over three blocks: against the
+    oracle and against the stepped kernel; then a block of all-new keys that fills the table (reads set aside and inserted
+    after the table has grown, k_ec_deferred_fixed)"""
+    monkeypatch.setenv("F2Q_HOT_LEARN", learn)
+    guides = synth.make_library(300, length, 91)
+    kw = dict(mode="EC", start=str(start), length=length)
+    blocks = [sprinkle_symbols(synth.make_fastq(synth.Spec(seed=60 + k, n_reads=n, read_len=rl, start=start, p_sub=0.15, p_rand=0.05), guides), k, rate=0.0005)
+              for k, n in enumerate((9000, 20000, 40000))]
+    blocks.append(synth.make_fastq(synth.Spec(seed=70, n_reads=150000, read_len=rl, start=start, p_sub=0.0, p_rand=0.97), guides))
+    orc = O.Oracle(**kw)
+    res = []
+    for no_hot in ("0", "1"):
+        monkeypatch.setenv("F2Q_NO_HOT", no_hot)
+        with P.Counter(**kw) as c:
+            for fq in blocks:
+                if no_hot == "0":
+                    orc.count_fastq(fq)
+                c.count_block(fq)
+            _, stats = c.read_counts()
+            res.append((list(stats), c.ec_results()))
+    assert res[0][0] == orc.stats() and res[1] == res[0]
+    assert [(k, n) for k, n, _ in res[0][1]] == list(zip(orc.keys(), orc.counts()))
+
+
 def test_ec_hot_keys_table_fills_up(P, monkeypatch):
     """the table is sized for new keys at the rate seen while learning; a later block of all-new keys fills it, the
     inserts give up after F2Q_HOT_MAXPROBE slots and those reads are decided after the table has grown"""
