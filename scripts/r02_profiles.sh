@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r02_prof; mkdir -p $out
-for wl in cfg3_50M_10k_m1 cfg2_10M_1k_m0 cfg4_50M_100k_m1 cfg5a_50M_10k_anchor_m1 cfg5b_50M_anchor_ec cfg3_2win_50M_10k_m1 cfg5c_2pair_50M_10k_m1; do
+for wl in cfg3_50M_10k_m1 cfg2_10M_1k_m0 cfg4_50M_100k_m1 cfg5a_50M_10k_anchor_m1 cfg5b_50M_anchor_ec cfg3_2win_50M_10k_m1 cfg5c_2pair_50M_10k_m1 cfg3b_50M_fixed_ec; do
   timeout -k 10 400 python bench.py --workload $wl --steps 10 --warmup 2 --no-extras > $out/${wl}_bench.json 2> $out/${wl}_bench.err || echo "bench $wl failed"
   ( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/${wl}_stats -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-pmc --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$out/${wl}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/${wl}_stats.err ) || echo "stats $wl failed"
   f=$(ls -t $out/${wl}_stats/*/*kernel_stats.csv | head -1); cp $f $out/${wl}_kernel_stats.csv
