@@ -215,12 +215,12 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
             // exact probes: up to 4 reads x 2 slots in flight per lane
             uint32_t s[4]; bool pend[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { pend[j] = (res[j] == R_NEAR); s[j] = hash32(key[j], ex.bits); }
+            for (int j = 0; j < 4; j++) { pend[j] = (res[j] == R_NEAR); s[j] = packed_start(key[j], ex.bits); }
             while (pend[0] | pend[1] | pend[2] | pend[3]) {
                 uint64_t v0[4], v1[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    if (pend[j]) { v0[j] = ptab[ex.off + s[j]]; v1[j] = ptab[ex.off + ((s[j] + 1u) & exm)]; }
+                    if (pend[j]) { const Slot2 pr = packed_pair(ptab, ex.off + s[j]); v0[j] = pr.a; v1[j] = pr.b; }   // one 16-byte load
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -436,12 +436,12 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_multi4(const RunDev
                 if (pk.len == 0u) continue;                           // no feature has k parts: nothing to hit (misses stay R_NEAR)
                 uint32_t s[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) s[j] = hash32(key[j], ex.bits);
+                for (int j = 0; j < 4; j++) s[j] = packed_start(key[j], ex.bits);
                 while (mine[0] | mine[1] | mine[2] | mine[3]) {
                     uint64_t v0[4], v1[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (mine[j]) { v0[j] = ptab[ex.off + s[j]]; v1[j] = ptab[ex.off + ((s[j] + 1u) & exm)]; }
+                        if (mine[j]) { const Slot2 pr = packed_pair(ptab, ex.off + s[j]); v0[j] = pr.a; v1[j] = pr.b; }
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (!mine[j]) continue;

@@ -264,6 +264,21 @@ F2Q_HD uint32_t hash32(uint64_t k, uint32_t bits)
     x *= 0xC2B2AE35u;
     return x >> (32u - bits);
 }
+// packed tables: a probe sequence starts at an even slot, so that the two slots of a round are one aligned 16-byte load
+F2Q_HD uint32_t packed_start(uint64_t k, uint32_t bits) { return hash32(k, bits) & ~1u; }
+// the pair of slots at even index s of a packed table
+struct Slot2 { uint64_t a, b; };
+template <class PT>
+F2Q_HD Slot2 packed_pair(PT ptab, uint32_t at)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+    const v2 v = *reinterpret_cast<const v2 F2Q_GLOBAL *>(ptab + at);
+    return Slot2{v.x, v.y};
+#else
+    return Slot2{ptab[at], ptab[at + 1]};
+#endif
+}
 
 F2Q_HD uint8_t up8(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
 F2Q_HD bool q_fails(uint8_t c, int thr) { return c >= 33 && (int)c <= thr; }
@@ -1079,10 +1094,11 @@ F2Q_HD int packed_exact(const LibDev &lib, const PackedGroup &pk, uint64_t key)
 {
     const PackedPiece &e = pk.exact;
     const uint32_t m = (1u << e.bits) - 1u, ib = pk.ib;
-    uint32_t s = hash32(key, e.bits);
+    uint32_t s = packed_start(key, e.bits);
     const auto ptab = gp(lib.ptab);
     for (;;) {
-        uint64_t v0 = ptab[e.off + s], v1 = ptab[e.off + ((s + 1) & m)];
+        const Slot2 pr = packed_pair(ptab, e.off + s);
+        const uint64_t v0 = pr.a, v1 = pr.b;
         if (v0 != KEY_EMPTY && (v0 >> ib) == key) return (int)(v0 & ((1ull << ib) - 1ull));
         if (v0 == KEY_EMPTY) return -1;
         if (v1 != KEY_EMPTY && (v1 >> ib) == key) return (int)(v1 & ((1ull << ib) - 1ull));
@@ -1136,9 +1152,9 @@ F2Q_HD void packed_near(const LibDev &lib, const PackedGroup &pk, uint64_t key, 
     for (uint32_t p = 0; p < 4; p++) {
         if (p < np) {
             const PackedPiece pd = pk.piece[p];
-            s0[p] = hash32((key >> pd.shift) & pd.mask, pd.bits);
-            v0[p] = ptab[pd.off + s0[p]];                                   // the chain's first two slots: at load
-            v1[p] = ptab[pd.off + ((s0[p] + 1u) & ((1u << pd.bits) - 1u))];  // factor <= 0.25 most chains end here
+            s0[p] = packed_start((key >> pd.shift) & pd.mask, pd.bits);
+            const Slot2 pr = packed_pair(ptab, pd.off + s0[p]);             // the chain's first two slots, one 16-byte load: at
+            v0[p] = pr.a; v1[p] = pr.b;                                      // load factor <= 0.25 most chains end here
         } else { s0[p] = 0; v0[p] = KEY_EMPTY; v1[p] = KEY_EMPTY; }
     }
 #pragma unroll
@@ -1147,7 +1163,7 @@ F2Q_HD void packed_near(const LibDev &lib, const PackedGroup &pk, uint64_t key, 
         const PackedPiece pd = pk.piece[p];
         if ((forced2 >> pd.shift) & pd.mask) continue;                       // this piece can never agree
         const uint32_t m = (1u << pd.bits) - 1u;
-        uint32_t s = p < 4 ? s0[p < 4 ? p : 0] : hash32((key >> pd.shift) & pd.mask, pd.bits);
+        uint32_t s = p < 4 ? s0[p < 4 ? p : 0] : packed_start((key >> pd.shift) & pd.mask, pd.bits);
         uint64_t v = p < 4 ? v0[p < 4 ? p : 0] : ptab[pd.off + s];
         uint64_t vn = p < 4 ? v1[p < 4 ? p : 0] : KEY_EMPTY;
         bool have_next = p < 4;

@@ -68,7 +68,7 @@ inline void table_insert(std::vector<uint64_t> &keys, std::vector<uint32_t> &idx
 
 inline void packed_insert(std::vector<uint64_t> &tab, const PackedPiece &pd, uint64_t hashed, uint64_t slot)
 {
-    uint32_t m = (1u << pd.bits) - 1u, s = hash32(hashed, pd.bits);
+    uint32_t m = (1u << pd.bits) - 1u, s = packed_start(hashed, pd.bits);   // (lookups fetch aligned pairs of slots)
     while (tab[pd.off + s] != KEY_EMPTY) s = (s + 1) & m;
     tab[pd.off + s] = slot;
 }
@@ -89,6 +89,7 @@ inline void build_packed(HostIndex &ix, const std::vector<uint32_t> &ids, int le
     const uint32_t bits = table_bits((uint32_t)ids.size()) + 1;          // load factor <= 0.25
     if (bits > 30) return;
     g.len = (uint32_t)len; g.ib = ib; g.n_pieces = (uint32_t)P;
+    if (ix.ptab.size() & 1u) ix.ptab.push_back(KEY_EMPTY);              // tables start at even slots: 16-byte aligned pairs
     uint32_t off = (uint32_t)ix.ptab.size();
     g.exact.off = off; g.exact.bits = bits; g.exact.shift = 0; g.exact.mask = ~0ull; off += 1u << bits;
     for (int p = 0; p < P; p++) {
