@@ -11,6 +11,7 @@
 // kernels
 // ===============================================================================================
 #define F2Q_HIST_MAX 24576u     // features whose u32 histogram fits the workgroup's LDS budget (96 KiB)
+#define F2Q_HIST_RANGE 38912u   // features per pass of k_hist_ranges, which has a CU's LDS to itself (152 KiB)
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
@@ -1721,14 +1722,14 @@ __global__ __launch_bounds__(256) void k_ec_hot_relink(EcDev ec, EcHot hot)
 
 // Large libraries (no per-workgroup LDS histogram of the whole library): the counting kernel leaves the feature index
 // of every read in hit_buf; here workgroup (range, part) histograms the indices of its part that fall into its range
-// of F2Q_HIST_MAX features in LDS and writes that stretch of slab row `part`.  hit_buf is read n_ranges times, from
+// of F2Q_HIST_RANGE features in LDS and writes that stretch of slab row `part`.  hit_buf is read n_ranges times, from
 // the Infinity Cache when it fits (4 B per read).
 __global__ __launch_bounds__(1024) void k_hist_ranges(const uint32_t *__restrict__ hit_buf, uint64_t n_slots, uint32_t nf,
                                                        uint32_t n_parts, uint32_t *__restrict__ slab)
 {
     extern __shared__ uint32_t rh[];
     const uint32_t range = blockIdx.x / n_parts, part = blockIdx.x % n_parts;
-    const uint32_t f0 = range * F2Q_HIST_MAX, fn = (nf - f0) < F2Q_HIST_MAX ? (nf - f0) : F2Q_HIST_MAX;
+    const uint32_t f0 = range * F2Q_HIST_RANGE, fn = (nf - f0) < F2Q_HIST_RANGE ? (nf - f0) : F2Q_HIST_RANGE;
     for (uint32_t i = threadIdx.x; i < fn; i += 1024u) rh[i] = 0;
     __syncthreads();
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));

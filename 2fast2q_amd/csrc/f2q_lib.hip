@@ -730,7 +730,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
             auto kern = lds ? (spec52 ? k_count_fixed4<true, 5, 2> : k_count_fixed4<true, 0, 0>)
                             : (spec52 ? k_count_fixed4<false, 5, 2> : k_count_fixed4<false, 0, 0>);
             const uint32_t nf_ = c->lib_h.n_features;
-            const uint32_t n_ranges = lds ? 1u : (nf_ + F2Q_HIST_MAX - 1) / F2Q_HIST_MAX;
+            const uint32_t n_ranges = lds ? 1u : (nf_ + F2Q_HIST_RANGE - 1) / F2Q_HIST_RANGE;
             const uint32_t n_parts = lds ? grid : std::max<uint32_t>(1u, (uint32_t)c->n_cu / n_ranges);
             {
                 // slab rows: one per counting workgroup (LDS histogram) or one per part of k_hist_ranges; stats rows per workgroup
@@ -759,7 +759,8 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
             hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, pb, acc);
             HIPC(c, hipGetLastError());
             if (!lds && nf_) {
-                hipLaunchKernelGGL(k_hist_ranges, dim3(n_ranges * n_parts), dim3(1024), (size_t)F2Q_HIST_MAX * 4, c->stream,
+                (void)hipFuncSetAttribute((const void *)k_hist_ranges, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F2Q_HIST_RANGE * 4));
+                hipLaunchKernelGGL(k_hist_ranges, dim3(n_ranges * n_parts), dim3(1024), (size_t)F2Q_HIST_RANGE * 4, c->stream,
                                    c->hit_buf_d, (uint64_t)pb.n_slots, nf_, n_parts, c->slab_d);
                 HIPC(c, hipGetLastError());
                 launches++;
