@@ -145,7 +145,9 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
 #define STAMP4(i) do {} while (0)
 #endif
 
-    // a hit: LDS histogram, or (large library) the feature index is stored at the read's slot for k_hist_ranges
+    // a hit: LDS histogram, or (large library) the feature index is stored at the read's slot for k_hist_ranges.  The
+    // exact hits of a lane's four reads leave as ONE 16-byte store that also clears the slots of the other reads (no
+    // memset of hit_buf); a hit found later by the near search overwrites its word.
     auto count_hit = [&](uint32_t idx, uint64_t slot) {
         if (USE_LDS) atomicAdd(&hist[idx], 1u);
         else gpw(acc.hit_buf)[slot] = idx;
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
         int res[4] = {R_SKIP, R_SKIP, R_SKIP, R_SKIP};
         uint64_t key[4] = {0, 0, 0, 0};
         uint32_t forced[4] = {0, 0, 0, 0};
+        uint32_t hid[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};       // !USE_LDS: feature of each read, so far
         if (tile < pb.n_tiles) {
             constexpr int QR = NQ ? NQ : F2Q_MAXQROWS, BR = NB ? NB : F2Q_MAXBROWS;
             constexpr bool NT = true;                    // tile rows are streamed once: keep L2 for the tables
@@ -227,9 +230,9 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 for (int j = 0; j < 4; j++) {
                     if (!pend[j]) continue;
                     if (v0[j] == KEY_EMPTY) pend[j] = false;
-                    else if ((v0[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v0[j] & imask), (uint64_t)tile * F2Q_TILE + 4u * lane + j); }
+                    else if ((v0[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; if (USE_LDS) count_hit((uint32_t)(v0[j] & imask), 0u); else hid[j] = (uint32_t)(v0[j] & imask); }
                     else if (v1[j] == KEY_EMPTY) pend[j] = false;
-                    else if ((v1[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; count_hit((uint32_t)(v1[j] & imask), (uint64_t)tile * F2Q_TILE + 4u * lane + j); }
+                    else if ((v1[j] >> ib) == key[j]) { pend[j] = false; res[j] = R_PERFECT; if (USE_LDS) count_hit((uint32_t)(v1[j] & imask), 0u); else hid[j] = (uint32_t)(v1[j] & imask); }
                     else s[j] = (s[j] + 2u) & exm;
                 }
             }
@@ -240,13 +243,18 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 if (res[j] == R_SLOW) {                    // clipped window / odd geometry: the one-read routine
                     uint32_t idx = 0;
                     int r1 = slow_read(runp, libp, &pb, tile, 4u * lane + (uint32_t)j, &idx);
-                    if (r1 == 1 || r1 == 2) count_hit(idx, (uint64_t)tile * F2Q_TILE + 4u * lane + j);
+                    if (r1 == 1 || r1 == 2) { if (USE_LDS) count_hit(idx, 0u); else hid[j] = idx; }
                     res[j] = r1;
                 } else if (res[j] == R_NEAR) {
                     if (do_near) npush++; else res[j] = R_NONALIGNED;
                 } else if (res[j] == R_FORCED) npush++;
                 st0 += (res[j] != R_SKIP); st1 += (res[j] == R_PERFECT); st2 += (res[j] == R_IMPERFECT);
                 st3 += (res[j] == R_NONALIGNED); st4 += (res[j] == R_QFAIL);
+            }
+            if (!USE_LDS) {
+                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                v4 hv; hv.x = hid[0]; hv.y = hid[1]; hv.z = hid[2]; hv.w = hid[3];
+                *reinterpret_cast<v4 F2Q_GLOBAL *>(gpw(acc.hit_buf) + (uint64_t)tile * F2Q_TILE + 4u * lane) = hv;
             }
             {
                 // ring slots by a wave prefix sum of npush (0..4) over three ballots -- no LDS atomics

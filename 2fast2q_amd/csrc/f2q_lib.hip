@@ -753,8 +753,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
                     HIPC(c, hipMalloc((void **)&c->hit_buf_d, pb.n_slots * sizeof(uint32_t)));
                     c->hit_buf_n = pb.n_slots;
                 }
-                HIPC(c, hipMemsetAsync(c->hit_buf_d, 0xFF, pb.n_slots * sizeof(uint32_t), c->stream));
-                acc.hit_buf = c->hit_buf_d;
+                acc.hit_buf = c->hit_buf_d;                          // (the kernel writes every slot: no clearing)
             }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_V2_THREADS), shmem, c->stream, c->run_d, c->lib_d, pb, acc);
             HIPC(c, hipGetLastError());
