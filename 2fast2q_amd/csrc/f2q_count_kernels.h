@@ -1224,9 +1224,17 @@ __device__ __forceinline__ U4 lds_u4(const uint32_t *p)
     const v4 v = *reinterpret_cast<const v4 *>(p);              // ds_read_b128
     return U4{v.x, v.y, v.z, v.w};
 }
-__device__ __forceinline__ uint32_t hot_match(const U4 &t, uint32_t tag, uint32_t bucket)
+// slot of key k in the workgroup's copy of the hot keys (two buckets of two key words), or F2Q_HOT_NONE
+struct HotPair { unsigned long long a, b; };
+__device__ __forceinline__ HotPair lds_k2(const unsigned long long *p)
 {
-    return t.x == tag ? 4u * bucket : t.y == tag ? 4u * bucket + 1u : t.z == tag ? 4u * bucket + 2u : t.w == tag ? 4u * bucket + 3u : F2Q_HOT_NONE;
+    typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+    const v2 v = *reinterpret_cast<const v2 *>(p);              // ds_read_b128
+    return HotPair{v.x, v.y};
+}
+__device__ __forceinline__ uint32_t hot_slot_of(const HotPair &p1, const HotPair &p2, const HotProbe &q, unsigned long long k)
+{
+    return p1.a == k ? 2u * q.b1 : p1.b == k ? 2u * q.b1 + 1u : p2.a == k ? 2u * q.b2 : p2.b == k ? 2u * q.b2 + 1u : F2Q_HOT_NONE;
 }
 
 // an entry of the list of reads set aside: slot of the view, kind (1: byte-exact routine), window start and length
@@ -1254,23 +1262,22 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
     unsigned long long *const defer_n = ec.ctr + F2Q_CTR_ASIDE;
     constexpr int NQW = 8 * NW;
     extern __shared__ uint32_t hot_smem[];
-    uint32_t *tg = hot_smem;                                    // [F2Q_HOT_SLOTS] tags
-    uint32_t *cnt = hot_smem + F2Q_HOT_SLOTS;                   // [F2Q_HOT_SLOTS] hits of this workgroup
+    unsigned long long *hk = reinterpret_cast<unsigned long long *>(hot_smem);   // [F2Q_HOT_SLOTS] key words
+    uint32_t *cnt = hot_smem + 2u * F2Q_HOT_SLOTS;              // [F2Q_HOT_SLOTS] hits of this workgroup
     const RunDev &run = *runp;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, slot_in_tile = tid & (F2Q_TILE - 1u), group = tid / F2Q_TILE;
     {
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(hot.tags);
-        v4 *dst = reinterpret_cast<v4 *>(tg);
-        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 4u; i += F2Q_HOT_THREADS) dst[i] = src[i];
+        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(hot.keys);
+        v4 *dst = reinterpret_cast<v4 *>(hk);
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 2u; i += F2Q_HOT_THREADS) dst[i] = src[i];
         for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_HOT_THREADS) cnt[i] = 0;
     }
     __syncthreads();
+    const unsigned long long first_max = gp(hot.meta)[0];       // a read at or past it cannot lower a hot key's first read
     const uint32_t ah_w = phred_add_hi(run.thr), ah_u = phred_add_hi(run.thr_up), ah_d = phred_add_hi(run.thr_down);
     uint32_t w_reads = 0, w_pass = 0, w_qfail = 0;              // this wave's counters (scalar registers)
     uint32_t n_new = 0;
-    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
-    const v2u64 F2Q_GLOBAL *kf = (const v2u64 F2Q_GLOBAL *)gp(hot.kf);
 
     struct Planes { uint32_t lo[NW], hi[NW], q[NQW], len; };
     const auto b_base = gp(pb.bases) + slot_in_tile, q_base = gp(pb.qual) + slot_in_tile;
@@ -1349,22 +1356,11 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
             if (sm && lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(sm));
         }
         const HotProbe q = hot_probe(k);
-        const U4 t1 = lds_u4(tg + 4u * q.b1), t2 = lds_u4(tg + 4u * q.b2);
-        const uint32_t c1 = hot_match(t1, q.tag, q.b1), c2 = hot_match(t2, q.tag, q.b2);
-        uint32_t s = c1 != F2Q_HOT_NONE ? c1 : c2;
-        bool hit = false;
+        const HotPair p1 = lds_k2(hk + 2u * q.b1), p2 = lds_k2(hk + 2u * q.b2);
+        const uint32_t s = hot_slot_of(p1, p2, q, k);
         unsigned long long gi = 0;
-        if (ins) {
-            gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
-            if (s != F2Q_HOT_NONE) {
-                v2u64 e = kf[s];
-                hit = e.x == k && gi >= e.y;
-                if (!hit && c1 != F2Q_HOT_NONE && c2 != F2Q_HOT_NONE) {     // another key with the same tag sat in bucket 1
-                    s = c2; e = kf[s];
-                    hit = e.x == k && gi >= e.y;
-                }
-            }
-        }
+        if (ins) gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+        const bool hit = ins && s != F2Q_HOT_NONE && gi >= first_max;
         bool full = false;
         if (hit) atomicAdd(&cnt[s], 1u);
         else if (ins) {
@@ -1534,20 +1530,20 @@ __global__ __launch_bounds__(F2Q_FH_THREADS) void k_extract_fixed4_hot(const Run
                                                                        unsigned long long *__restrict__ defer, uint64_t slot_base, uint64_t defer_cap)
 {
     extern __shared__ uint32_t hot_smem[];
-    uint32_t *tg = hot_smem, *cnt = hot_smem + F2Q_HOT_SLOTS;
+    unsigned long long *hk = reinterpret_cast<unsigned long long *>(hot_smem);
+    uint32_t *cnt = hot_smem + 2u * F2Q_HOT_SLOTS;
     const RunDev &run = *runp;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     {
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(hot.tags);
-        v4 *dst = reinterpret_cast<v4 *>(tg);
-        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 4u; i += F2Q_FH_THREADS) dst[i] = src[i];
+        const v4 F2Q_GLOBAL *src = (const v4 F2Q_GLOBAL *)gp(hot.keys);
+        v4 *dst = reinterpret_cast<v4 *>(hk);
+        for (uint32_t i = tid; i < F2Q_HOT_SLOTS / 2u; i += F2Q_FH_THREADS) dst[i] = src[i];
         for (uint32_t i = tid; i < F2Q_HOT_SLOTS; i += F2Q_FH_THREADS) cnt[i] = 0;
     }
     __syncthreads();
+    const unsigned long long first_max = gp(hot.meta)[0];
     const FixedGeom g = fixed_geom(run);
-    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
-    const v2u64 F2Q_GLOBAL *kf = (const v2u64 F2Q_GLOBAL *)gp(hot.kf);
     unsigned long long st[5] = {0, 0, 0, 0, 0};
     uint32_t n_new = 0;
     for (uint32_t base = blockIdx.x * F2Q_FH_WAVES; base < pb.n_tiles; base += gridDim.x * F2Q_FH_WAVES) {
@@ -1581,7 +1577,7 @@ __global__ __launch_bounds__(F2Q_FH_THREADS) void k_extract_fixed4_hot(const Run
                 if (r < g.nq) fixed4_qrow(g, r, qrow[r], bad);
         }
         // the four reads' tag buckets are read together, then verified and counted one after the other
-        unsigned long long k[4]; bool ins[4]; HotProbe q[4]; U4 t1[4], t2[4];
+        unsigned long long k[4]; bool ins[4]; HotProbe q[4]; HotPair p1[4], p2[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t l = pb.len ? (((j < 2 ? len01 : len23) >> (16 * (j & 1))) & 0xFFFFu) : pb.rmax;
@@ -1594,23 +1590,16 @@ __global__ __launch_bounds__(F2Q_FH_THREADS) void k_extract_fixed4_hot(const Run
             const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
             k[j] = ((unsigned long long)L << 58) | key;
             q[j] = hot_probe(k[j]);
-            t1[j] = lds_u4(tg + 4u * q[j].b1); t2[j] = lds_u4(tg + 4u * q[j].b2);
+            p1[j] = lds_k2(hk + 2u * q[j].b1); p2[j] = lds_k2(hk + 2u * q[j].b2);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + 4u * lane + (uint32_t)j;
-            const uint32_t c1 = hot_match(t1[j], q[j].tag, q[j].b1), c2 = hot_match(t2[j], q[j].tag, q[j].b2);
-            uint32_t s = c1 != F2Q_HOT_NONE ? c1 : c2;
-            bool hit = false, full = false;
+            const uint32_t s = hot_slot_of(p1[j], p2[j], q[j], k[j]);
+            bool full = false;
             unsigned long long gi = 0;
-            if (ins[j]) {
-                gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
-                if (s != F2Q_HOT_NONE) {
-                    v2u64 e = kf[s];
-                    hit = e.x == k[j] && gi >= e.y;
-                    if (!hit && c1 != F2Q_HOT_NONE && c2 != F2Q_HOT_NONE) { s = c2; e = kf[s]; hit = e.x == k[j] && gi >= e.y; }
-                }
-            }
+            if (ins[j]) gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
+            const bool hit = ins[j] && s != F2Q_HOT_NONE && gi >= first_max;
             if (hit) { atomicAdd(&cnt[s], 1u); st[1]++; }
             else if (ins[j]) {
                 uint32_t ts = 0; unsigned long long before = 0;
@@ -1701,23 +1690,24 @@ __global__ __launch_bounds__(256) void k_ec_hot_build(EcDev ec, EcHot hot)
     const HotProbe q = hot_probe(k);
     for (int pass = 0; pass < 2; pass++) {
         const uint32_t b = pass ? q.b2 : q.b1;
-        for (uint32_t j = 0; j < 4u; j++) {
-            // slots of a bucket fill in order and every key scans them in order: a tag is unique within its bucket
-            const uint32_t old = atomicCAS(&hot.tags[4u * b + j], 0u, q.tag);
-            if (old == 0u) {
-                hot.kf[2u * (4u * b + j)] = k; hot.kf[2u * (4u * b + j) + 1u] = ec.k64_first[s];
-                hot.slot[4u * b + j] = s;
+        for (uint32_t j = 0; j < 2u; j++) {
+            const unsigned long long old = atomicCAS(&hot.keys[2u * b + j], KEY_EMPTY, k);
+            if (old == KEY_EMPTY) {
+                hot.slot[2u * b + j] = s;
+                atomicMax(&hot.meta[0], ec.k64_first[s]);
                 return;
             }
-            if (old == q.tag) return;                            // same tag in the bucket: this key stays cold
+            if (old == k) return;                                // (a slot noted twice)
         }
     }
+    // both buckets full: this key stays cold
 }
 __global__ __launch_bounds__(256) void k_ec_hot_relink(EcDev ec, EcHot hot)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= F2Q_HOT_SLOTS || hot.tags[i] == 0u) return;
-    const unsigned long long k = hot.kf[2u * i];
+    if (i >= F2Q_HOT_SLOTS) return;
+    const unsigned long long k = hot.keys[i];
+    if (k == KEY_EMPTY) return;
     uint32_t s = hash32(k ^ (k >> 29), 32) & ec.k64_mask;
     for (uint32_t guard = 0; guard <= ec.k64_mask; guard++) {
         const unsigned long long v = ec.k64_slots[s];
@@ -1725,7 +1715,7 @@ __global__ __launch_bounds__(256) void k_ec_hot_relink(EcDev ec, EcHot hot)
         if (v == KEY_EMPTY) break;
         s = (s + 1) & ec.k64_mask;
     }
-    hot.tags[i] = 0u;                                            // cannot happen (growth keeps every key); stay exact anyway
+    hot.keys[i] = KEY_EMPTY;                                     // cannot happen (growth keeps every key); stay exact anyway
 }
 
 // Large libraries (no per-workgroup LDS histogram of the whole library): the counting kernel leaves the feature index

@@ -207,13 +207,14 @@ F2Q_HD uint32_t ec64_text(unsigned long long word, char *out)
 
 // Extract+Count, hot keys.  Counting a read costs one device-scope atomic on a scattered address (~10 G/s on MI355X), and
 // in a screen most reads carry one of a few thousand keys.  Once the single-word table has seen F2Q_HOT_LEARN reads, the
-// keys seen most often are copied into a small 2-choice bucket table (4 tags per bucket, one ds_read_b128); a workgroup
-// holds the tags and a u32 counter per slot in LDS, counts hits there and adds each counter to the table once, when it
-// ends.  A tag hit is checked against the full key (kf, 16 bytes, L2-resident), so the result is exact; a read that comes
-// before the key's recorded first read takes the ordinary insert, which lowers the minimum.
-#define F2Q_HOT_BUCKETS 4096u
-#define F2Q_HOT_SLOTS (4u * F2Q_HOT_BUCKETS)
-#define F2Q_HOT_CAP 11264u           // keys admitted: load <= 0.69
+// keys seen most often are copied into a small 2-choice bucket table (2 full key words per bucket, one ds_read_b128);
+// a workgroup holds the keys and a u32 counter per slot in LDS, counts hits there and adds each counter to the table
+// once, when it ends.  The LDS copy holds the whole key word, so a hit needs no memory access at all.  A hot key's
+// first read is already in the table; only a read with an index BELOW every hot key's recorded first read (meta[0]:
+// blocks counted out of order) must take the ordinary insert, which lowers the minimum.
+#define F2Q_HOT_BUCKETS 6656u
+#define F2Q_HOT_SLOTS (2u * F2Q_HOT_BUCKETS)     // 104 KiB of keys + 52 KiB of counters
+#define F2Q_HOT_CAP 11264u           // keys admitted: load <= 0.85
 #define F2Q_HOT_MINCOUNT 6u          // a key becomes a candidate when the learning reads bring its count to this
 #define F2Q_HOT_CAND 32768u          // candidates noted (in the order they got there: the most frequent first)
 #define F2Q_HOT_NONE 0xFFFFFFFFu
@@ -224,21 +225,20 @@ F2Q_HD uint32_t ec64_text(unsigned long long word, char *out)
 #define F2Q_CTR_CAND 6               // candidates noted so far in this sample
 #define F2Q_CTR_WORDS 8
 struct EcHot {
-    uint32_t *tags;                  // [F2Q_HOT_SLOTS]; 0 = empty
-    unsigned long long *kf;          // [F2Q_HOT_SLOTS][2]: the key's table word, its first read when the set was built
+    unsigned long long *keys;        // [F2Q_HOT_SLOTS] key words, ~0 = empty (the image the workgroups copy into LDS)
     uint32_t *slot;                  // [F2Q_HOT_SLOTS]: the key's slot in the single-word table
     uint32_t *cand;                  // [F2Q_HOT_CAND]: table slots of the candidates
+    unsigned long long *meta;        // [0] the highest first-read index recorded for a hot key when the set was built
 };
-struct HotProbe { uint32_t b1, b2, tag; };
+struct HotProbe { uint32_t b1, b2; };
 F2Q_HD HotProbe hot_probe(unsigned long long k)
 {
     unsigned long long h = (k ^ (k >> 31)) * 0x9E3779B97F4A7C15ull;
     h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
     HotProbe q;
-    q.b1 = (uint32_t)h & (F2Q_HOT_BUCKETS - 1u);
-    q.b2 = (uint32_t)(h >> 12) & (F2Q_HOT_BUCKETS - 1u);
-    if (q.b2 == q.b1) q.b2 = q.b1 ^ 1u;
-    q.tag = (uint32_t)(h >> 32) | 1u;
+    q.b1 = (uint32_t)(((h & 0xFFFFFFFFull) * F2Q_HOT_BUCKETS) >> 32);
+    q.b2 = (uint32_t)(((h >> 32) * F2Q_HOT_BUCKETS) >> 32);
+    if (q.b2 == q.b1) q.b2 = q.b1 + 1u == F2Q_HOT_BUCKETS ? 0u : q.b1 + 1u;
     return q;
 }
 

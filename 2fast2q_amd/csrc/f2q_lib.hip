@@ -799,11 +799,11 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
 // ---- Extract+Count, anchored tiles, hot keys in LDS (EcHot, k_extract_anchor_hot) ---------------------------------
 static int hot_arrays(f2q_ctx *c)
 {
-    if (c->hot.tags) return F2Q_OK;
+    if (c->hot.keys) return F2Q_OK;
     int rc;
-    if ((rc = dev_alloc(c, (size_t)F2Q_HOT_SLOTS, &c->hot.tags, c->hot_allocs, 0))) return rc;
-    if ((rc = dev_alloc(c, (size_t)F2Q_HOT_SLOTS * 2, &c->hot.kf, c->hot_allocs))) return rc;
+    if ((rc = dev_alloc(c, (size_t)F2Q_HOT_SLOTS, &c->hot.keys, c->hot_allocs, 0xFF))) return rc;
     if ((rc = dev_alloc(c, (size_t)F2Q_HOT_SLOTS, &c->hot.slot, c->hot_allocs))) return rc;
+    if ((rc = dev_alloc(c, (size_t)2, &c->hot.meta, c->hot_allocs, 0))) return rc;
     return dev_alloc(c, (size_t)F2Q_HOT_CAND, &c->hot.cand, c->hot_allocs);
 }
 // the set from the candidates the learning launches noted
@@ -811,7 +811,8 @@ static int hot_build(f2q_ctx *c)
 {
     int rc = hot_arrays(c);
     if (rc) return rc;
-    HIPC(c, hipMemsetAsync(c->hot.tags, 0, (size_t)F2Q_HOT_SLOTS * 4, c->stream));
+    HIPC(c, hipMemsetAsync(c->hot.keys, 0xFF, (size_t)F2Q_HOT_SLOTS * 8, c->stream));
+    HIPC(c, hipMemsetAsync(c->hot.meta, 0, 16, c->stream));
     if (c->ec.k64_slots) {
         hipLaunchKernelGGL(k_ec_hot_build, dim3((F2Q_HOT_CAP + 255) / 256), dim3(256), 0, c->stream, c->ec, c->hot);
         HIPC(c, hipGetLastError());
@@ -843,10 +844,10 @@ static int launch_hot(f2q_ctx *c, const PackedBlock &v, uint64_t slot_base, Accu
 {
     int rc = hot_arrays(c);
     if (rc) return rc;
-    if (learning) HIPC(c, hipMemsetAsync(c->hot.tags, 0, (size_t)F2Q_HOT_SLOTS * 4, c->stream));   // an empty set
+    if (learning) HIPC(c, hipMemsetAsync(c->hot.keys, 0xFF, (size_t)F2Q_HOT_SLOTS * 8, c->stream));   // an empty set
     const int nw = (int)v.planar_nw, kb = c->plan.kb;
     const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
-    const size_t shmem = (size_t)F2Q_HOT_SLOTS * 8;
+    const size_t shmem = (size_t)F2Q_HOT_SLOTS * 12;             // key words + counters
     if (!v.planar_nw) {
         // fixed window: one wave per tile
         const uint32_t wgs = (v.n_tiles + F2Q_FH_WAVES - 1) / F2Q_FH_WAVES;
