@@ -337,6 +337,59 @@ def test_ec_hot_keys_fixed_window(P, monkeypatch, learn, start, length, rl):
     assert [(k, n) for k, n, _ in res[0][1]] == list(zip(orc.keys(), orc.counts()))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_ec_hot_keys_fuzz(P, monkeypatch, seed):
+    """random Extract+Count runs through the hot-key kernels: anchored or fixed window, learning threshold, number and size
+    of blocks, share of repeated / novel / 'N' / long keys, block order -- keys, counts and first-seen order against the
+    oracle (which sees the blocks in read-index order)"""
+    import random
+    rng = random.Random(1000 + seed)
+    monkeypatch.setenv("F2Q_HOT_LEARN", str(rng.choice([64, 700, 5000, 40000])))
+    anchored = rng.random() < 0.6
+    glen = rng.choice([12, 20, 29]) if not anchored else rng.choice([16, 20, 33])
+    guides = synth.make_library(rng.choice([40, 400, 3000]), glen, 500 + seed)
+    if anchored:
+        kw = dict(mode="EC", upstream=UP, miss_search_up=rng.choice([0, 1]))
+        if rng.random() < 0.7:
+            kw.update(downstream=DOWN, miss_search_down=kw["miss_search_up"])
+        else:
+            kw["length"] = glen
+    else:
+        kw = dict(mode="EC", start=str(rng.choice([0, 5, 16])), length=glen)
+    blocks = []
+    for k in range(rng.choice([1, 2, 4])):
+        n = rng.choice([3000, 20000, 70000])
+        p_rand = rng.choice([0.02, 0.3, 0.9])
+        if anchored:
+            spec = dict(seed=seed * 10 + k, n_reads=n if glen <= 31 else min(n, 20000), read_len=150 if glen < 30 else 120, cassette=True, up=UP, down=DOWN,
+                        max_offset=60, p_sub=rng.choice([0.0, 0.2]), p_rand=p_rand, p_n=rng.choice([0.0, 0.05]))
+            if glen <= 31:
+                with P.Counter(features=guides, miss=1) as gen:
+                    fq = bytes(gen.synth_fastq(**spec))
+            else:
+                fq = synth.make_fastq(synth.Spec(**spec), guides)      # (the device generator plants guides of <= 31 bases)
+        else:
+            fq = synth.make_fastq(synth.Spec(seed=seed * 10 + k, n_reads=n, read_len=int(kw["start"]) + glen + rng.choice([0, 7]),
+                                             start=int(kw["start"]), p_sub=rng.choice([0.0, 0.2]), p_rand=p_rand, p_n=rng.choice([0.0, 0.05])), guides)
+        blocks.append(sprinkle_symbols(fq, k, rate=rng.choice([0.0, 0.0004])))
+    orc = O.Oracle(**kw)
+    for fq in blocks:
+        orc.count_fastq(fq)
+    bases, b0 = [], 0
+    for fq in blocks:
+        bases.append(b0); b0 += fq.count(b"\n") // 4
+    order = list(range(len(blocks)))
+    if rng.random() < 0.5:
+        rng.shuffle(order)                                          # blocks counted out of read-index order
+    with P.Counter(**kw) as c:
+        for i in order:
+            c.set_read_base(bases[i])
+            c.count_block(blocks[i])
+        _, stats = c.read_counts()
+        assert list(stats) == orc.stats()
+        assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+
+
 def test_ec_hot_keys_table_fills_up(P, monkeypatch):
     """the table is sized for new keys at the rate seen while learning; a later block of all-new keys fills it, the
     inserts give up after F2Q_HOT_MAXPROBE slots and those reads are decided after the table has grown"""
