@@ -732,6 +732,27 @@ def test_lds_histogram_overflow_protocol(P, monkeypatch):
     assert (ca, sa) == (cb, sb) and sa[0] == 40_000_000 and sum(ca) == sa[1] + sa[2] and min(ca) > 10_000_000
 
 
+def test_range_histogram_with_popular_features(P, monkeypatch):
+    """a library too large for a per-workgroup histogram (hit_buf + k_hist_ranges) with almost every read on two features
+    of different range passes, against the general kernel"""
+    lib = P.binding.synth_library(77, 30000, 20)
+    spec = dict(seed=5, n_reads=12_000_000, read_len=60, p_sub=0.02, p_rand=0.0, p_n=0.0)
+    res = []
+    for env in ({}, {"F2Q_FORCE_GENERAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with P.Counter(features=lib, miss=1, length=20, start="0") as c:
+            blk = c.synth_create(guides=[lib[3], lib[29999]], **spec)
+            t = c.count_resident(blk)
+            counts, stats = c.read_counts()
+            blk.free()
+        for k in env:
+            monkeypatch.delenv(k)
+        res.append((list(counts), list(stats), t["general_reads"]))
+    assert res[0][2] == 0 and res[1][2] == 12_000_000 and res[0][:2] == res[1][:2]
+    assert res[0][0][3] > 5_000_000 and res[0][0][29999] > 5_000_000 and sum(res[0][0]) == res[0][1][1] + res[0][1][2]
+
+
 def test_library_is_built_from_this_tree(P):
     """the .so the tests load carries the hash of the sources in this tree (no stale binary)"""
     import __graft_entry__ as g
