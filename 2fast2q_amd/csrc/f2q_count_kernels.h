@@ -1212,19 +1212,12 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_count_anchor_lt(const RunDe
 }
 
 // ---- anchored Extract+Count with the hot keys in LDS (EcHot, f2q_device.h) ------------------------------------------
-// k_count_anchor_lt's tile walk and extraction stage; the key of a passing window is looked up in the workgroup's copy
-// of the hot-key tags (two buckets, 2 x ds_read_b128), a tag hit is verified against the full key in global memory
-// (16 bytes, L2) and counted in an LDS counter; everything else takes the single-word table's insert.  Reads the
-// single-word table cannot hold (window over 29 bases, negative-index slices) are only noted in `defer`: the host
-// sizes the byte-string table for exactly those and k_ec_deferred decides them with the byte-exact routine.
-// The packer never flags reads of an Extract+Count run (the key holds the symbol itself), so there are no flag planes.
-__device__ __forceinline__ U4 lds_u4(const uint32_t *p)
-{
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    const v4 v = *reinterpret_cast<const v4 *>(p);              // ds_read_b128
-    return U4{v.x, v.y, v.z, v.w};
-}
-// slot of key k in the workgroup's copy of the hot keys (two buckets of two key words), or F2Q_HOT_NONE
+// k_count_anchor_lt's tile walk and extraction stage; the single-word form of a passing window's key is looked up in
+// the workgroup's copy of the hot keys (two buckets of two key words, 2 x ds_read_b128) and a hit is counted in an LDS
+// counter; everything else takes the single-word table's insert with a bounded probe sequence.  Reads that have no
+// single-word form (window over 29 bases, more than three 'N's), negative-index slices and reads that meet a full table
+// are only noted in `defer`: the host sizes the tables for exactly those, and k_ec_deferred_keys / k_ec_deferred_slow
+// decide them after the launch.  Reads whose only odd symbol is 'N' arrive flagged (a flag reads 'N').
 struct HotPair { unsigned long long a, b; };
 __device__ __forceinline__ HotPair lds_k2(const unsigned long long *p)
 {
