@@ -892,7 +892,10 @@ static int hot_aside(f2q_ctx *c, const PackedBlock &blk, Accum &acc, uint32_t &l
 {
     const unsigned long long n_def = ctr[F2Q_CTR_ASIDE], n_slow = ctr[F2Q_CTR_ASIDE_SLOW];
     if (!n_def) return F2Q_OK;
-    int rc = ec_reserve(c, n_slow, n_def, n_def * ((uint64_t)blk.rmax + F2Q_MAX_ITER), ctr);
+    // the raw records' kernel may still be adding entries: the counters read after the launch say too little then
+    const unsigned long long *known = ctr;
+    if (c->aux_busy) { HIPC(c, hipStreamSynchronize(c->aux_stream)); c->aux_busy = false; known = nullptr; }
+    int rc = ec_reserve(c, n_slow, n_def, n_def * ((uint64_t)blk.rmax + F2Q_MAX_ITER), known);
     if (rc) return rc;
     const uint32_t g = (uint32_t)std::min<uint64_t>((n_def + 255) / 256, (uint64_t)c->n_cu * 8u);
     if (n_def > n_slow) {
