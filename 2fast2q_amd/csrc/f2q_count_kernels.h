@@ -137,7 +137,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
     const uint32_t ib = lib.pk.ib, exm = (1u << ex.bits) - 1u;
     const uint64_t imask = (1ull << ib) - 1ull;
     const auto ptab = gp(lib.ptab);
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+    uint32_t st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;      // per lane and launch: far below 2^32
 #ifdef F2Q_STAMP
     unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, t0_ = 0, t1_;
 #define STAMP4(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)

@@ -723,7 +723,8 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
             launches++;
         } else if (v2) {
             const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
-            const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
+            uint32_t v2_mult = 2u; { const char *e = getenv("F2Q_V2_GRID"); if (e && atoi(e) > 0) v2_mult = (uint32_t)atoi(e); }
+            const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * v2_mult);
             const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 4);
             const FixedGeom fg = fixed_geom(c->run_h);
             const bool spec52 = !c->force_generic && fg.nq == 5 && fg.nb == 2 && c->run_h.thr >= 33;
