@@ -14,3 +14,5 @@ timeout -k 10 300 python bench.py --force-dist --no-pmc --no-cpu-baseline --no-e
 python -c "import json; d=json.load(open('$out/bench_nccl_1rank.json')); print('1 rank through RCCL:', round(d['value']), d['config'].get('collective'))"
 timeout -k 10 400 python bench.py --gpus 2 --dist-backend gloo --reads 50000000 --steps 5 > $out/bench_2rank_gloo.json 2> $out/bench_2rank_gloo.err
 python -c "import json; d=json.load(open('$out/bench_2rank_gloo.json')); print('2 ranks (gloo, one GPU):', round(d['value']), d['scaling'], d['config']['workload'], d['verify'].get('all_ranks_equal'))"
+timeout -k 10 400 python bench.py --gpus 4 --dist-backend gloo --reads 40000000 --steps 3 > $out/bench_4rank_gloo.json 2> $out/bench_4rank_gloo.err
+python -c "import json; d=json.load(open('$out/bench_4rank_gloo.json')); print('4 ranks (gloo, one GPU):', round(d['value']), d['scaling'], d['n_gpus'], d['config']['workload'], d['verify'])"
