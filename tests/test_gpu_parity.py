@@ -1,5 +1,6 @@
 """GPU parity tests: the HIP path (through the C-ABI of libf2q_hip.so) against the golden vectors
 captured from the reference, and against the oracle on seeded synthetic inputs.  Bit-exact."""
+import os
 import pytest
 
 import synth
@@ -337,7 +338,7 @@ def test_ec_hot_keys_fixed_window(P, monkeypatch, learn, start, length, rl):
     assert [(k, n) for k, n, _ in res[0][1]] == list(zip(orc.keys(), orc.counts()))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("F2Q_EC_FUZZ_SEEDS", "10"))))     # one-off long runs: more seeds
 def test_ec_hot_keys_fuzz(P, monkeypatch, seed):
     """random Extract+Count runs through the hot-key kernels: anchored or fixed window, learning threshold, number and size
     of blocks, share of repeated / novel / 'N' / long keys, block order -- keys, counts and first-seen order against the
