@@ -16,7 +16,7 @@ STAT_NAMES = ("reads", "perfect_counter", "imperfect_counter", "non_aligned_coun
 
 EXPORTS = (
     "f2q_version", "f2q_build_id", "f2q_create", "f2q_destroy", "f2q_last_error", "f2q_set_features", "f2q_count_block",
-    "f2q_count_file", "f2q_count_file_shard", "f2q_file_pieces", "f2q_census_pieces", "f2q_count_pieces", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_block_info",
+    "f2q_count_file", "f2q_count_file_shard", "f2q_file_pieces", "f2q_census_pieces", "f2q_count_pieces", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_count_resident_queued", "f2q_queued_times", "f2q_block_info",
     "f2q_block_free", "f2q_synth_fastq", "f2q_synth_library", "f2q_reset_counts", "f2q_read_counts",
     "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base", "f2q_synth_guides",
 )
@@ -141,6 +141,8 @@ def load(path=None):
     L.f2q_synth_create.argtypes = [vp, C.POINTER(Synth), C.POINTER(vp)]
     L.f2q_block_from_fastq.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
     L.f2q_count_resident.argtypes = [vp, vp, C.POINTER(Timing)]
+    L.f2q_count_resident_queued.argtypes = [vp, vp]
+    L.f2q_queued_times.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
     L.f2q_block_info.argtypes = [vp, u64p, u64p, u64p]
     L.f2q_block_free.argtypes = [vp, vp]; L.f2q_block_free.restype = None
     L.f2q_synth_fastq.argtypes = [vp, C.POINTER(Synth), C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_size_t)]
@@ -343,6 +345,17 @@ class Counter:
         t = Timing()
         self._check(self._L.f2q_count_resident(self._h, block._h, C.byref(t)))
         return t.as_dict()
+
+    def count_resident_queued(self, block):
+        """queue the hot path over a resident block on the context's stream without waiting (see queued_times)"""
+        self._check(self._L.f2q_count_resident_queued(self._h, block._h))
+
+    def queued_times(self, cap=4096):
+        """wait for the stream; kernel time (ms) of every step queued since the last call"""
+        buf = (C.c_float * cap)()
+        n = C.c_uint32()
+        self._check(self._L.f2q_queued_times(self._h, buf, cap, C.byref(n)))
+        return [float(buf[i]) for i in range(min(n.value, cap))]
 
     def set_read_base(self, first_read_index):
         self._check(self._L.f2q_set_read_base(self._h, int(first_read_index)))

@@ -45,6 +45,8 @@ struct f2q_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    std::vector<hipEvent_t> q_ev;          // f2q_count_resident_queued: a pair of events per queued step
+    uint32_t q_n = 0;                      // steps queued since the last f2q_queued_times
     hipStream_t copy_stream = nullptr;   // f2q_count_file: the text of the next piece travels while this one is counted
     hipEvent_t ev_copy = nullptr;
     RunDev run_h{};
@@ -345,6 +347,7 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
     if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    for (hipEvent_t e : c->q_ev) (void)hipEventDestroy(e);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->ev_aux0) (void)hipEventDestroy(c->ev_aux0);
     if (c->ev_aux1) (void)hipEventDestroy(c->ev_aux1);
@@ -919,8 +922,9 @@ static int hot_aside(f2q_ctx *c, const PackedBlock &blk, Accum &acc, uint32_t &l
     return F2Q_OK;
 }
 
-static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
+static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr)
 {
+    if (!k0) { k0 = c->ev_k0; k1 = c->ev_k1; }          // (a queued step brings its own pair)
     if (c->prm.mode == 0 && !c->have_lib) return fail(c, F2Q_ESTATE, "f2q_set_features must be called before counting in Counter mode");
     Accum acc{c->acc_d, c->acc_d + (c->acc_n - 5), nullptr, nullptr, nullptr, nullptr};
 #ifdef F2Q_STAMP
@@ -929,7 +933,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
     acc.stamp = stamp_d;
 #endif
     uint32_t launches = 0;
-    HIPC(c, hipEventRecord(c->ev_k0, c->stream));
+    HIPC(c, hipEventRecord(k0, c->stream));
     if (c->prm.mode == 0) {
         int rc = launch_view(c, b->pb, b->rb, acc, launches);
         if (rc) return rc;
@@ -1032,7 +1036,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
             if ((rc = launch_view(c, nop, v, acc, launches))) return rc;
         }
     }
-    HIPC(c, hipEventRecord(c->ev_k1, c->stream));
+    HIPC(c, hipEventRecord(k1, c->stream));
     c->reads_seen += b->n_reads;
 #ifdef F2Q_STAMP
     { unsigned long long h[4]; (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(h, acc.stamp, 32, hipMemcpyDeviceToHost);
@@ -1043,9 +1047,9 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
                        (double)tot / ((double)b->pb.n_tiles * 4)); }
 #endif
     if (t) {
-        HIPC(c, hipEventSynchronize(c->ev_k1));
+        HIPC(c, hipEventSynchronize(k1));
         float ms = 0;
-        HIPC(c, hipEventElapsedTime(&ms, c->ev_k0, c->ev_k1));
+        HIPC(c, hipEventElapsedTime(&ms, k0, k1));
         t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
         t->fast_reads = b->n_reads - b->n_general; t->launches = launches;
     }
@@ -1073,6 +1077,33 @@ extern "C" int f2q_count_resident(f2q_ctx *c, const f2q_block *b, f2q_timing *t)
         float ms = 0; HIPC(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
         t->total_ms = ms;
     }
+    return F2Q_OK;
+}
+
+extern "C" int f2q_count_resident_queued(f2q_ctx *c, const f2q_block *b)
+{
+    if (!c || !b) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    while (c->q_ev.size() < 2 * ((size_t)c->q_n + 1)) {
+        hipEvent_t e = nullptr;
+        HIPC(c, hipEventCreate(&e));
+        c->q_ev.push_back(e);
+    }
+    int rc = launch_block(c, b, nullptr, c->q_ev[2 * (size_t)c->q_n], c->q_ev[2 * (size_t)c->q_n + 1]);
+    if (rc) return rc;
+    c->q_n++;
+    return F2Q_OK;
+}
+
+extern "C" int f2q_queued_times(f2q_ctx *c, float *kernel_ms, uint32_t cap, uint32_t *n)
+{
+    if (!c || !n) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    *n = c->q_n;
+    for (uint32_t i = 0; i < c->q_n && i < cap && kernel_ms; i++)
+        HIPC(c, hipEventElapsedTime(&kernel_ms[i], c->q_ev[2 * (size_t)i], c->q_ev[2 * (size_t)i + 1]));
+    c->q_n = 0;
     return F2Q_OK;
 }
 

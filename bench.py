@@ -304,18 +304,21 @@ def timed_steps(c, blk, steps, warmup, allreduce=None, barrier=None, sync=None):
         barrier()
     if sync:
         sync()
-    kern = []
+    c.queued_times()                               # (forget steps queued earlier)
     t0 = time.perf_counter()
     for _ in range(steps):
         c.reset()                                  # each step is a whole job: zeroed accumulators -> count -> all-reduce
-        kern.append(c.count_resident(blk)["kernel_ms"])   # launches on the context's stream; HIP events of that stream
-        if allreduce:
+        c.count_resident_queued(blk)               # queued on the context's stream, no host wait between steps; every step
+        if allreduce:                              # is stamped with its own pair of HIP events on that stream
             allreduce()
     if sync:
         sync()
     if barrier:
         barrier()
-    return time.perf_counter() - t0, sum(kern) / len(kern)
+    dt = time.perf_counter() - t0
+    kern = c.queued_times()                        # kernel time of each of the K steps, read after the timed region
+    assert len(kern) == steps, (len(kern), steps)
+    return dt, sum(kern) / len(kern)
 
 
 def main():

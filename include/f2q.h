@@ -162,6 +162,11 @@ int f2q_count_pieces(f2q_ctx *ctx, const char *path, uint32_t rank, uint32_t wor
 int f2q_synth_create(f2q_ctx *ctx, const f2q_synth *spec, f2q_block **out);
 int f2q_block_from_fastq(f2q_ctx *ctx, const uint8_t *fastq, size_t nbytes, f2q_block **out);
 int f2q_count_resident(f2q_ctx *ctx, const f2q_block *blk, f2q_timing *t);
+/* The same without waiting: the launches are queued on the context's stream and the step gets its own pair of HIP
+ * events; f2q_queued_times waits for the stream, returns the kernel time of every step queued since the last call
+ * (kernel_ms[0 .. min(*n, cap))) and forgets them.  For callers that queue block after block (bench.py's timed loop). */
+int f2q_count_resident_queued(f2q_ctx *ctx, const f2q_block *blk);
+int f2q_queued_times(f2q_ctx *ctx, float *kernel_ms, uint32_t cap, uint32_t *n);
 int f2q_block_info(const f2q_block *blk, uint64_t *n_reads, uint64_t *n_general, uint64_t *device_bytes);
 void f2q_block_free(f2q_ctx *ctx, f2q_block *blk);
 

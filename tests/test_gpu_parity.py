@@ -754,6 +754,26 @@ def test_range_histogram_with_popular_features(P, monkeypatch):
     assert res[0][0][3] > 5_000_000 and res[0][0][29999] > 5_000_000 and sum(res[0][0]) == res[0][1][1] + res[0][1][2]
 
 
+@pytest.mark.parametrize("mode", ["C", "EC"])
+def test_queued_steps_match_waited_steps(P, mode):
+    """f2q_count_resident_queued: steps queued back to back (what bench.py times) give what the waited calls give, and
+    every step comes back with its own kernel time"""
+    guides = synth.make_library(500, 20, 5)
+    kw = dict(features=guides, miss=1) if mode == "C" else dict(mode="EC", start="0", length=20)
+    with P.Counter(**kw) as c:
+        blk = c.synth_create(guides=guides, seed=9, n_reads=300_000) if mode == "EC" else c.synth_create(seed=9, n_reads=300_000)
+        c.reset(); c.count_resident(blk); c.count_resident(blk); c.count_resident(blk)
+        want = [list(x) for x in c.read_counts()] + [c.ec_results() if mode == "EC" else None]
+        assert c.queued_times() == []
+        c.reset()
+        for _ in range(3):
+            c.count_resident_queued(blk)
+        times = c.queued_times()
+        assert len(times) == 3 and all(t > 0 for t in times) and c.queued_times() == []
+        assert [list(x) for x in c.read_counts()] + [c.ec_results() if mode == "EC" else None] == want
+        blk.free()
+
+
 def test_library_is_built_from_this_tree(P):
     """the .so the tests load carries the hash of the sources in this tree (no stale binary)"""
     import __graft_entry__ as g
