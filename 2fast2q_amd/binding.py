@@ -56,7 +56,7 @@ class Synth(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("reads", C.c_uint64),
                 ("fast_reads", C.c_uint64), ("general_reads", C.c_uint64), ("launches", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("path", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

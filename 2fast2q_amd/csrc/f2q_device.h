@@ -97,6 +97,32 @@ struct LtDesc {
     const uint32_t *feat_of;           // [F2Q_LT_SLOTS] feature of a table-0 slot (unused slots: 0)
 };
 
+// "Partitioned tables": the same tag tables for a uniform library too large for one workgroup's LDS (BASELINE config 4:
+// 100 k guides).  The features are dealt into n_parts partitions by a hash of their half 0; every partition has its own
+// table 0 (F2Q_LT_SLOTS tags: what one workgroup holds in LDS next to its u16 histogram), so exact hits and the
+// neighbours that share the query's half 0 are decided in LDS by the workgroups of the query's partition.  Neighbours
+// that share half 1 can sit in any partition: ONE table 1 over all features stays in global memory (2 << bb1 tags, L2
+// resident) and is probed only by the reads without an exact hit.  Features are renumbered partition by partition
+// ("gid"); a hit is counted by table-0 slot inside its partition or, when found through table 1, by table-1 slot.
+#define F2Q_PT_MAXP 32u
+#define F2Q_PT_FILL 12800u         // features per partition the builder aims at (of F2Q_LT_SLOTS = 16384 tag slots)
+#define F2Q_PT_SPILL (1u << 30)    // PtDesc::spill when the tags leave bit 30 free
+#define F2Q_PT_EMPTY_SPILL 0xFFFFFFFEu   // an empty first slot of a bucket that carries the mark (equals no tag: the free bits are set)
+struct PtDesc {
+    uint32_t ok, n_parts;              // ok = 1: tables built
+    uint32_t len, hb0, hb1, bb1;       // feature length, bits of the halves, bucket bits of table 1
+    uint32_t max_part;                 // features of the largest partition
+    uint32_t spill;                    // 0, or the bit of a table-1 bucket's FIRST tag that says "a feature whose first-choice bucket this is
+                                       // sits in its second-choice bucket": clear = the second bucket need not be read
+    const uint32_t *tags0;             // [n_parts][F2Q_LT_SLOTS]
+    const uint32_t *tags1;             // [2 << bb1]
+    const uint32_t *pstart;            // [n_parts + 1]: partition p holds gids pstart[p] .. pstart[p + 1] - 1
+    const uint16_t *slot0_of;          // [n_features] by gid: table-0 slot inside the feature's partition
+    const uint32_t *slot1_of;          // [n_features] by gid: table-1 slot
+    const uint32_t *feat_of;           // [n_features] by gid: index of the feature in the library
+    const uint32_t *feat0_of;          // [n_parts][F2Q_LT_SLOTS]: library index of the feature in a table-0 slot (u16 counter hand-off)
+};
+
 // "General keys": an index of ALL features as byte strings, by length -- what the byte-exact routine looks keys up in
 // that are no plain ACGT string of <= 31 bases (':'-joined multi-part keys, long features, odd symbols), and every key of
 // a run whose library holds such features.  Per length group an exact table (hash of all bytes) and m+1 pigeonhole
@@ -125,6 +151,7 @@ struct LibDev {
     PackedGroup mpk[F2Q_MW_MAX];       // multi-window runs: packed tables of the k-part features, k = index + 1 (len = k * l)
     uint32_t mw_ok, mw_pad;            // 1: every feature a multi-window key can equal or approach is a k-part feature
     LtDesc lt;
+    PtDesc pt;
     GkDesc gk;
     const uint64_t *tab_keys;          // open-addressing slots: 2-bit feature key or KEY_EMPTY
     const uint32_t *tab_idx;           // feature index of the slot
@@ -1248,13 +1275,23 @@ F2Q_HD uint32_t lt_perm(uint32_t h, uint32_t bits, int c)
     return v;
 }
 // choice c of half value h of table t: bucket and what (entry >> ob) must equal for "same half" (ob = bits of the other half)
-F2Q_HD void lt_hash(uint32_t h, uint32_t bits, uint32_t ob, int c, uint32_t &bucket, uint32_t &cmp)
+// bb: bucket-index bits of the table (F2Q_LT_BBITS for a table held in LDS; the global table 1 of a partitioned library is larger)
+F2Q_HD void lt_hash(uint32_t h, uint32_t bits, uint32_t ob, int c, uint32_t &bucket, uint32_t &cmp, uint32_t bb = F2Q_LT_BBITS)
 {
     const uint32_t v = lt_perm(h, bits, c);
-    bucket = v & (F2Q_LT_BUCKETS - 1u);
-    cmp = ((uint32_t)c << (31u - ob)) | (v >> F2Q_LT_BBITS);
+    bucket = v & ((1u << bb) - 1u);
+    cmp = ((uint32_t)c << (31u - ob)) | (v >> bb);
 }
 F2Q_HD uint32_t lt_tag(uint32_t cmp, uint32_t other, uint32_t ob) { return (cmp << ob) | other; }
+// partition of a half-0 value (PtDesc): two full-rate 24-bit multiplies; every feature and every query with that half 0
+F2Q_HD uint32_t pt_part(uint32_t h0, uint32_t n_parts)
+{
+    const uint32_t x = lt_mul24(h0 ^ (h0 >> 11), 0xB5297Au);
+    return lt_mul24((x >> 8) & 0xFFFFu, n_parts) >> 16;
+}
+// a candidate read as it travels from the scatter pass to the count pass of a partitioned library: the 2L key bits, then
+// one bit per window base that is no ACGT symbol (a forced mismatch)
+F2Q_HD unsigned long long pt_entry(uint64_t key, uint32_t forced, uint32_t L) { return key | ((unsigned long long)forced << (2u * L)); }
 
 F2Q_HD uint32_t ham2_32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1283,15 +1320,16 @@ F2Q_HD uint32_t spread16(uint32_t v)          // bit i -> bit 2i, i < 16
 struct U2 { uint32_t x, y; };
 // the four bucket addresses of a key (table-0 choices 0/1, table-1 choices 0/1) and their "same half" comparands
 struct LtProbe { uint32_t b[4], cmp[4], h0, h1; };
-F2Q_HD LtProbe lt_probe(const LtDesc &lt, uint64_t key)
+// bb1: bucket bits of table 1 (a partitioned library keeps ONE table 1 for all partitions, in global memory)
+F2Q_HD LtProbe lt_probe(const LtDesc &lt, uint64_t key, uint32_t bb1 = F2Q_LT_BBITS)
 {
     LtProbe q;
     q.h0 = (uint32_t)key & ((1u << lt.hb0) - 1u);
     q.h1 = (uint32_t)(key >> lt.hb0);
     lt_hash(q.h0, lt.hb0, lt.hb1, 0, q.b[0], q.cmp[0]);
     lt_hash(q.h0, lt.hb0, lt.hb1, 1, q.b[1], q.cmp[1]);
-    lt_hash(q.h1, lt.hb1, lt.hb0, 0, q.b[2], q.cmp[2]);
-    lt_hash(q.h1, lt.hb1, lt.hb0, 1, q.b[3], q.cmp[3]);
+    lt_hash(q.h1, lt.hb1, lt.hb0, 0, q.b[2], q.cmp[2], bb1);
+    lt_hash(q.h1, lt.hb1, lt.hb0, 1, q.b[3], q.cmp[3], bb1);
     return q;
 }
 // exact hit among the two table-0 buckets: slot or -1 (branch-free: a key sits in at most one slot)
@@ -1304,7 +1342,7 @@ F2Q_HD int lt_exact(const LtDesc &lt, const LtProbe &q, const U2 &e0, const U2 &
 }
 // candidates at distance exactly 1 among the four buckets e[0..3] (see the section comment).  forced: one bit per base
 // of the window that mismatches every feature.  Returns the number of candidates; for one of them: hit = table (0/1)
-// << 16 | its slot in that table, hitw = its tag.
+// << 31 | its slot in that table, hitw = its tag.
 F2Q_HD uint32_t lt_near1(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], uint32_t forced, uint32_t &hit, uint32_t &hitw)
 {
     const uint32_t l0 = lt.hb0 >> 1;
@@ -1335,7 +1373,7 @@ F2Q_HD uint32_t lt_near1(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], u
             const uint32_t d = ham2_32(((w ^ oq) & om) & keep) + nf;
             const bool c = open & same & (d == 1u);
             n += (uint32_t)c;
-            hit = c ? (((uint32_t)t1 << 16) | (2u * q.b[k] + (uint32_t)i)) : hit;
+            hit = c ? (((uint32_t)t1 << 31) | (2u * q.b[k] + (uint32_t)i)) : hit;
             hitw = c ? w : hitw;
         }
     }
@@ -1395,8 +1433,10 @@ F2Q_HD LtSide lt_side(uint32_t want0, uint32_t want1, uint32_t limit, uint32_t b
 // The Counter-mode decision of one read from its four buckets: is it a perfect hit, is it the unique feature at
 // distance 1, and the histogram slot to bump.  NEAR = run with --m 1 (false: --m 0, table 0 only, e[2..3] unused).
 // rd0(bucket) reads a table-0 bucket (needed when the unique neighbour was found through table 1).
-struct LtVerdict { LtPred perfect, imperfect; uint32_t slot; };
-template <bool NEAR, class RD>
+// T1SLOT (partitioned libraries): a hit found through table 1 is reported as its TABLE-1 slot with `via1` set, instead of
+// being translated into the feature's table-0 slot (that slot lives in another partition's table); rd0 is then unused.
+struct LtVerdict { LtPred perfect, imperfect, via1; uint32_t slot; };
+template <bool NEAR, bool T1SLOT = false, class RD>
 F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4], uint32_t forced, RD rd0)
 {
     const uint32_t w0 = lt_tag(q.cmp[0], q.h1, lt.hb1), w1 = lt_tag(q.cmp[1], q.h1, lt.hb1);
@@ -1408,6 +1448,7 @@ F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4],
     LtPred fast = LT_NOT(a.multi);
     if (!NEAR) fast = fast & unforced;
     LtPred perfect = unforced & fast & a.any & LT_P(a.x == 0u), near = perfect & LT_NOT(perfect);      // near = false
+    LtPred through1 = near;                                              // false
     uint32_t slot = a.slot;
     if (NEAR) {
         w2 = lt_tag(q.cmp[2], q.h0, lt.hb0); w3 = lt_tag(q.cmp[3], q.h0, lt.hb0);
@@ -1436,10 +1477,12 @@ F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4],
             near = near | g;
             via1 = via1 | (g & LT_P(in0));
         }
-        if (LT_TRUE(via1)) slot = lt_slot_of_t1(lt, q, b.x ^ LT_SEL(b.first, w2, w3), rd0);
+        if (T1SLOT) { slot = LT_SEL(via1, b.slot, slot); through1 = via1; }
+        else if (LT_TRUE(via1)) slot = lt_slot_of_t1(lt, q, b.x ^ LT_SEL(b.first, w2, w3), rd0);
     }
     // several features sharing one of the query's halves: the general routine
     int sres = 0;
+    bool sv1 = false;
     if (!LT_TRUE(fast)) {
         sres = R_NONALIGNED;
         const int ex = forced == 0u ? lt_exact(lt, q, e[0], e[1]) : -1;
@@ -1452,13 +1495,15 @@ F2Q_HD LtVerdict lt_decide(const LtDesc &lt, const LtProbe &q, const U2 (&e)[4],
             uint32_t hit = 0, hitw = 0;
             if (lt_near1(lt, q, e, forced, hit, hitw) == 1u) {
                 sres = R_IMPERFECT;
-                slot = (hit >> 16) ? lt_slot_of_t1(lt, q, hitw, rd0) : (hit & 0xFFFFu);
+                if (T1SLOT) { slot = hit & 0x7FFFFFFFu; sv1 = (hit >> 31) != 0u; }
+                else slot = (hit >> 31) ? lt_slot_of_t1(lt, q, hitw, rd0) : (hit & 0x7FFFFFFFu);
             }
         }
     }
     LtVerdict v;
     v.perfect = perfect | LT_P(sres == R_PERFECT);
     v.imperfect = near | LT_P(sres == R_IMPERFECT);
+    v.via1 = through1 | LT_P(sv1);
     v.slot = slot;
     return v;
 }

@@ -31,6 +31,11 @@ struct HostIndex {
     LtDesc lt{};
     std::vector<uint32_t> lt_tags, lt_feat_of;
     std::vector<uint16_t> lt_slot_of;
+    // partitioned tables (f2q_device.h: PtDesc); pt.ok == 0: not applicable / not needed / the build failed
+    PtDesc pt{};
+    int pt_force_parts = 0;              // > 0: build that many partitions whatever the library's size (set before build_index)
+    std::vector<uint32_t> pt_tags0, pt_tags1, pt_pstart, pt_slot1_of, pt_feat_of, pt_feat0_of;
+    std::vector<uint16_t> pt_slot0_of;
     // general keys (GkDesc): byte-string index of all features by length
     std::vector<GkGroup> gk_groups;
     std::vector<uint32_t> gk_tab, gk_ids, gk_fwoff;
@@ -125,9 +130,50 @@ inline int parts_key(const uint8_t *s, uint32_t n, int l, int max_parts, uint64_
     return k;
 }
 
-// LDS tables for a library whose features all have the window length (f2q_device.h, "LDS tables").  Cuckoo
-// insertion with two buckets of two slots per key and table: an occupied pair of buckets evicts one resident
-// (round robin over the four slots), which moves to its other bucket, up to a bounded number of moves.
+// Cuckoo insertion of one tag table (f2q_device.h, "LDS tables"): every feature of `ids` goes into one of the two buckets
+// (of two slots) its half t selects, bb bucket-index bits; an occupied pair of buckets evicts a random resident, which
+// moves to its other bucket, up to a bounded number of moves.  tg / ow: 2 << bb tags and the feature held by each slot.
+inline bool lt_cuckoo(const HostIndex &ix, const std::vector<uint32_t> &ids, int t, uint32_t hb0, uint32_t hb1, uint32_t bb,
+                      uint32_t *tg, uint32_t *ow)
+{
+    const uint32_t hb = t ? hb1 : hb0, ob = t ? hb0 : hb1;
+    auto halves = [&](uint32_t f, uint32_t &h, uint32_t &o) {
+        const uint64_t k = ix.key2[f];
+        const uint32_t h0 = (uint32_t)k & ((1u << hb0) - 1u), h1 = (uint32_t)(k >> hb0);
+        h = t ? h1 : h0; o = t ? h0 : h1;
+    };
+    uint64_t rs = 0x9E3779B97F4A7C15ull + (uint64_t)t;       // fixed seed: the tables are a pure function of the library
+    for (uint32_t f0 : ids) {
+        uint32_t f = f0, from = ~0u;                 // slot the feature in hand was evicted from
+        bool placed = false;
+        for (int moves = 0; moves < 20000 && !placed; moves++) {
+            uint32_t h, o; halves(f, h, o);
+            uint32_t b[2], cmp[2];
+            lt_hash(h, hb, ob, 0, b[0], cmp[0], bb); lt_hash(h, hb, ob, 1, b[1], cmp[1], bb);
+            for (int c = 0; c < 2 && !placed; c++)
+                for (int i = 0; i < 2 && !placed; i++) {
+                    const uint32_t s = 2u * b[c] + (uint32_t)i;
+                    if (tg[s] == F2Q_LT_EMPTY) { tg[s] = lt_tag(cmp[c], o, ob); ow[s] = f; placed = true; }
+                }
+            if (placed) break;
+            // random walk: evict a random resident of the four slots, not the one just vacated for this feature
+            uint32_t s; int c;
+            for (int tries = 0;; tries++) {
+                rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+                c = (int)((rs >> 33) & 1u);
+                s = 2u * b[c] + (uint32_t)((rs >> 34) & 1u);
+                if (s != from || tries > 8) break;
+            }
+            const uint32_t g = ow[s];
+            tg[s] = lt_tag(cmp[c], o, ob); ow[s] = f;
+            from = s; f = g;
+        }
+        if (!placed) return false;
+    }
+    return true;
+}
+
+// LDS tables for a library whose features all have the window length (f2q_device.h, "LDS tables").
 inline void build_lt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, int miss)
 {
     memset(&ix.lt, 0, sizeof ix.lt);
@@ -138,49 +184,84 @@ inline void build_lt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, i
     lt.len = (uint32_t)len; lt.hb0 = 2u * (uint32_t)(len / 2); lt.hb1 = 2u * (uint32_t)len - lt.hb0;
     std::vector<uint32_t> tags(2 * (size_t)F2Q_LT_SLOTS, F2Q_LT_EMPTY);
     std::vector<uint32_t> owner(2 * (size_t)F2Q_LT_SLOTS, ~0u);         // feature stored in a slot
-    for (int t = 0; t < 2; t++) {
-        uint32_t *tg = tags.data() + (size_t)t * F2Q_LT_SLOTS, *ow = owner.data() + (size_t)t * F2Q_LT_SLOTS;
-        const uint32_t hb = t ? lt.hb1 : lt.hb0, ob = t ? lt.hb0 : lt.hb1;
-        auto halves = [&](uint32_t f, uint32_t &h, uint32_t &o) {
-            const uint64_t k = ix.key2[f];
-            const uint32_t h0 = (uint32_t)k & ((1u << lt.hb0) - 1u), h1 = (uint32_t)(k >> lt.hb0);
-            h = t ? h1 : h0; o = t ? h0 : h1;
-        };
-        uint64_t rs = 0x9E3779B97F4A7C15ull + (uint64_t)t;       // fixed seed: the tables are a pure function of the library
-        for (uint32_t f0 : ids) {
-            uint32_t f = f0, from = ~0u;                 // slot the feature in hand was evicted from
-            bool placed = false;
-            for (int moves = 0; moves < 20000 && !placed; moves++) {
-                uint32_t h, o; halves(f, h, o);
-                uint32_t b[2], cmp[2];
-                lt_hash(h, hb, ob, 0, b[0], cmp[0]); lt_hash(h, hb, ob, 1, b[1], cmp[1]);
-                for (int c = 0; c < 2 && !placed; c++)
-                    for (int i = 0; i < 2 && !placed; i++) {
-                        const uint32_t s = 2u * b[c] + (uint32_t)i;
-                        if (tg[s] == F2Q_LT_EMPTY) { tg[s] = lt_tag(cmp[c], o, ob); ow[s] = f; placed = true; }
-                    }
-                if (placed) break;
-                // random walk: evict a random resident of the four slots, not the one just vacated for this feature
-                uint32_t s; int c;
-                for (int tries = 0;; tries++) {
-                    rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
-                    c = (int)((rs >> 33) & 1u);
-                    s = 2u * b[c] + (uint32_t)((rs >> 34) & 1u);
-                    if (s != from || tries > 8) break;
-                }
-                const uint32_t g = ow[s];
-                tg[s] = lt_tag(cmp[c], o, ob); ow[s] = f;
-                from = s; f = g;
-            }
-            if (!placed) return;                       // no LDS tables for this library (lt.ok stays 0)
-        }
-    }
+    for (int t = 0; t < 2; t++)
+        if (!lt_cuckoo(ix, ids, t, lt.hb0, lt.hb1, F2Q_LT_BBITS, tags.data() + (size_t)t * F2Q_LT_SLOTS, owner.data() + (size_t)t * F2Q_LT_SLOTS))
+            return;                                    // no LDS tables for this library (lt.ok stays 0)
     ix.lt_slot_of.assign(ix.n_features, 0); ix.lt_feat_of.assign(F2Q_LT_SLOTS, 0);
     for (uint32_t s = 0; s < F2Q_LT_SLOTS; s++)
         if (owner[s] != ~0u) { ix.lt_slot_of[owner[s]] = (uint16_t)s; ix.lt_feat_of[s] = owner[s]; }
     ix.lt_tags.swap(tags);
     lt.ok = 1;
     ix.lt = lt;
+}
+
+// Partitioned tables (f2q_device.h: PtDesc) for a uniform library that is too large for one workgroup's LDS: the features
+// are dealt into partitions by pt_part(half 0); a table 0 per partition, one table 1 over all of them.  force_parts > 0
+// builds that many partitions whatever the library's size (tests, A/B runs).
+inline void build_pt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, int miss, int force_parts)
+{
+    memset(&ix.pt, 0, sizeof ix.pt);
+    ix.pt_tags0.assign(1, F2Q_LT_EMPTY); ix.pt_tags1.assign(1, F2Q_LT_EMPTY); ix.pt_pstart.assign(2, 0);
+    ix.pt_slot0_of.assign(1, 0); ix.pt_slot1_of.assign(1, 0); ix.pt_feat_of.assign(1, 0); ix.pt_feat0_of.assign(1, 0);
+    if (len < 14 || len > 21 || miss > 1 || ids.empty() || ids.size() != ix.n_features) return;
+    if (force_parts <= 0 && ix.lt.ok) return;                            // the whole library fits one workgroup's LDS
+    const uint32_t n = (uint32_t)ids.size();
+    PtDesc pt{};
+    pt.len = (uint32_t)len; pt.hb0 = 2u * (uint32_t)(len / 2); pt.hb1 = 2u * (uint32_t)len - pt.hb0;
+    // table 1: load <= 0.2, so that a bucket is seldom full and nearly every feature sits in its first-choice bucket (a
+    // lookup then reads ONE bucket: see PtDesc::spill); tag = [choice][half 1 above the bucket bits][half 0]
+    uint32_t bb1 = 4;
+    while ((2ull << bb1) < 5ull * n) bb1++;
+    if (bb1 > pt.hb1) bb1 = pt.hb1;
+    if ((2ull << bb1) < (uint64_t)n + n / 4 || 1u + (pt.hb1 - bb1) + pt.hb0 > 32u) return;
+    std::vector<uint32_t> tags1((size_t)2 << bb1, F2Q_LT_EMPTY), owner1((size_t)2 << bb1, ~0u);
+    if (!lt_cuckoo(ix, ids, 1, pt.hb0, pt.hb1, bb1, tags1.data(), owner1.data())) return;   // > 4 features share a half 1
+    uint32_t P = force_parts > 0 ? (uint32_t)force_parts : (n + F2Q_PT_FILL - 1) / F2Q_PT_FILL;
+    for (; P <= F2Q_PT_MAXP; P++) {
+        std::vector<std::vector<uint32_t>> by_part(P);
+        for (uint32_t f : ids) by_part[pt_part((uint32_t)ix.key2[f] & ((1u << pt.hb0) - 1u), P)].push_back(f);
+        std::vector<uint32_t> tags0((size_t)P * F2Q_LT_SLOTS, F2Q_LT_EMPTY), owner0((size_t)P * F2Q_LT_SLOTS, ~0u);
+        bool ok = true;
+        for (uint32_t p = 0; p < P && ok; p++)
+            ok = by_part[p].size() <= (size_t)(F2Q_LT_SLOTS * 0.87) &&
+                 lt_cuckoo(ix, by_part[p], 0, pt.hb0, pt.hb1, F2Q_LT_BBITS, tags0.data() + (size_t)p * F2Q_LT_SLOTS, owner0.data() + (size_t)p * F2Q_LT_SLOTS);
+        if (!ok) { if (force_parts > 0) return; continue; }            // a crowded partition: deal into one more
+        pt.n_parts = P; pt.bb1 = bb1;
+        ix.pt_pstart.assign(P + 1, 0);
+        ix.pt_feat_of.clear(); ix.pt_slot0_of.assign(n, 0); ix.pt_slot1_of.assign(n, 0);
+        ix.pt_feat0_of.assign((size_t)P * F2Q_LT_SLOTS, 0);
+        std::vector<uint32_t> gid_of(ix.n_features, 0);
+        for (uint32_t p = 0; p < P; p++) {
+            ix.pt_pstart[p] = (uint32_t)ix.pt_feat_of.size();
+            for (uint32_t f : by_part[p]) { gid_of[f] = (uint32_t)ix.pt_feat_of.size(); ix.pt_feat_of.push_back(f); }
+            pt.max_part = std::max<uint32_t>(pt.max_part, (uint32_t)by_part[p].size());
+            for (uint32_t s = 0; s < F2Q_LT_SLOTS; s++) {
+                const uint32_t f = owner0[(size_t)p * F2Q_LT_SLOTS + s];
+                if (f != ~0u) { ix.pt_slot0_of[gid_of[f]] = (uint16_t)s; ix.pt_feat0_of[(size_t)p * F2Q_LT_SLOTS + s] = f; }
+            }
+        }
+        ix.pt_pstart[P] = n;
+        for (size_t s = 0; s < owner1.size(); s++) if (owner1[s] != ~0u) ix.pt_slot1_of[gid_of[owner1[s]]] = (uint32_t)s;
+        // the mark on a first-choice bucket whose feature went to its second choice (bit 30 of the bucket's first tag,
+        // free when choice bit + the half-1 bits above the bucket index + half 0 stay below it)
+        if (pt.hb0 + (pt.hb1 - bb1) <= 30u) {
+            pt.spill = F2Q_PT_SPILL;
+            for (size_t s = 0; s < owner1.size(); s++) {
+                if (owner1[s] == ~0u) continue;
+                const uint32_t h1 = (uint32_t)(ix.key2[owner1[s]] >> pt.hb0);
+                uint32_t b0, c0;
+                lt_hash(h1, pt.hb1, pt.hb0, 0, b0, c0, bb1);
+                if ((uint32_t)(s >> 1) != b0) {                      // sits in its second-choice bucket
+                    uint32_t &w = tags1[2u * (size_t)b0];
+                    w = w == F2Q_LT_EMPTY ? F2Q_PT_EMPTY_SPILL : (w == F2Q_PT_EMPTY_SPILL ? w : (w | F2Q_PT_SPILL));
+                }
+            }
+        }
+        ix.pt_tags0.swap(tags0); ix.pt_tags1.swap(tags1);
+        pt.ok = 1;
+        ix.pt = pt;
+        return;
+    }
 }
 
 // byte-string index of ALL features, by length (f2q_device.h: GkDesc): exact table + m+1 pigeonhole piece tables per group
@@ -246,7 +327,7 @@ inline void build_gk(HostIndex &ix, int miss)
 // a multi-window run of that many windows, whose k-part features get packed tables of their own
 inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, uint32_t n, int miss, int packed_len = 0, int mw_windows = 0)
 {
-    ix = HostIndex();
+    { const int keep = ix.pt_force_parts; ix = HostIndex(); ix.pt_force_parts = keep; }
     ix.n_features = n;
     ix.feat_off.assign(offs, offs + n + 1);
     uint32_t base = offs[0];
@@ -322,6 +403,7 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
         ix.mw_ok = mw_ok ? 1u : 0u;
     }
     build_lt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss);
+    build_pt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss, ix.pt_force_parts);
     build_gk(ix, miss);
     ix.n_irregular = (uint32_t)ix.irr_ids.size();
     if (ix.irr_ids.empty()) ix.irr_ids.push_back(0);     // keep the device array non-empty

@@ -26,6 +26,7 @@
 using namespace f2q;
 
 #include "f2q_count_kernels.h"
+#include "f2q_part_kernels.h"
 #include "f2q_aux_kernels.h"
 
 // ===============================================================================================
@@ -89,12 +90,22 @@ struct f2q_ctx {
     uint64_t hot_learn = (uint64_t)1 << 18, ec_learned = 0;
     unsigned long long *defer_d = nullptr; size_t defer_cap = 0;
     uint64_t reads_seen = 0;             // global read index of the next block's read 0
+    uint32_t last_path = 0;              // F2Q_PATH_* of the last packed-tile launch (f2q_timing.path)
     int n_cu = 256;
     bool force_generic = false;           // F2Q_GENERIC=1: run-time window geometry even where a specialisation exists
     bool host_pack = false;               // F2Q_HOST_PACK=1: frame/classify/pack on the host (the round-1 first path; A/B runs)
     bool force_general = false;           // F2Q_FORCE_GENERAL=1: every read through the byte-exact general kernel (cross-checks)
     bool force_v1 = false;                // F2Q_FORCE_V1=1: keep the one-read-per-lane kernel (A/B runs)
     bool no_lt = false;                   // F2Q_NO_LT=1: never the LDS-table kernel (A/B runs, cross-checks)
+    bool no_pt = false;                   // F2Q_NO_PT=1: never the partitioned-table kernels (A/B runs, cross-checks)
+    uint64_t pt_chunk_reads = (uint64_t)1 << 26;   // F2Q_PT_CHUNK: most reads per scatter/count round of the partitioned path
+    uint64_t pt_min_reads = (uint64_t)1 << 21;     // F2Q_PT_MIN_READS: smaller blocks keep the packed-table kernel (three launches and the
+                                                   // tables' way into LDS do not pay for a block that small)
+    // scratch of the partitioned path (k_part_*): entry streams and their lengths, the two slabs, the stats rows
+    PartScratch pt_s{};
+    size_t pt_streams_n = 0, pt_cnt_n = 0, pt_slab0_n = 0, pt_slab1_n = 0;
+    uint32_t *pt_slab0_d = nullptr, *pt_slab1_d = nullptr;
+    unsigned long long *pt_stat_d = nullptr; size_t pt_stat_n = 0;
     // device memory freed by blocks / scratch is kept (idle, after a stream sync) for the next piece of the same
     // size class: a streamed file costs ~20 allocations per piece otherwise
     std::multimap<size_t, void *> dev_idle;
@@ -242,6 +253,16 @@ static int upload_lib(f2q_ctx *c)
         if ((rc = dev_upload(c, c->ix.lt_feat_of.data(), c->ix.lt_feat_of.size(), &lt_feat, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.lt_slot_of.data(), c->ix.lt_slot_of.size(), &lt_slot, c->lib_allocs))) return rc;
         L.lt = c->ix.lt; L.lt.tags = lt_tags; L.lt.feat_of = lt_feat; L.lt.slot_of = lt_slot;
+        uint32_t *pt_t0, *pt_t1, *pt_ps, *pt_s1, *pt_fo, *pt_f0; uint16_t *pt_s0;
+        if ((rc = dev_upload(c, c->ix.pt_tags0.data(), c->ix.pt_tags0.size(), &pt_t0, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.pt_tags1.data(), c->ix.pt_tags1.size(), &pt_t1, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.pt_pstart.data(), c->ix.pt_pstart.size(), &pt_ps, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.pt_slot0_of.data(), c->ix.pt_slot0_of.size(), &pt_s0, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.pt_slot1_of.data(), c->ix.pt_slot1_of.size(), &pt_s1, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.pt_feat_of.data(), c->ix.pt_feat_of.size(), &pt_fo, c->lib_allocs))) return rc;
+        if ((rc = dev_upload(c, c->ix.pt_feat0_of.data(), c->ix.pt_feat0_of.size(), &pt_f0, c->lib_allocs))) return rc;
+        L.pt = c->ix.pt; L.pt.tags0 = pt_t0; L.pt.tags1 = pt_t1; L.pt.pstart = pt_ps; L.pt.slot0_of = pt_s0; L.pt.slot1_of = pt_s1;
+        L.pt.feat_of = pt_fo; L.pt.feat0_of = pt_f0;
         GkGroup *gk_grp; uint32_t *gk_tab, *gk_ids;
         if ((rc = dev_upload(c, c->ix.gk_groups.data(), c->ix.gk_groups.size(), &gk_grp, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.gk_tab.data(), c->ix.gk_tab.size(), &gk_tab, c->lib_allocs))) return rc;
@@ -293,6 +314,10 @@ extern "C" int f2q_create(const f2q_params *p, f2q_ctx **out)
     { const char *fv = getenv("F2Q_GENERIC"); c->force_generic = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_NO_LT"); c->no_lt = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_NO_HOT"); c->no_hot = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_NO_PT"); c->no_pt = fv && fv[0] == '1'; }
+    { const char *fv = getenv("F2Q_PT_PARTS"); if (fv && atoi(fv) > 0) c->ix.pt_force_parts = std::min(atoi(fv), (int)F2Q_PT_MAXP); }
+    { const char *fv = getenv("F2Q_PT_CHUNK"); if (fv && atol(fv) > 0) c->pt_chunk_reads = (uint64_t)atol(fv); }
+    { const char *fv = getenv("F2Q_PT_MIN_READS"); if (fv && atol(fv) >= 0) c->pt_min_reads = (uint64_t)atol(fv); }
     { const char *fv = getenv("F2Q_HOT_LEARN"); if (fv && atol(fv) > 0) c->hot_learn = (uint64_t)atol(fv); }
     { const char *fv = getenv("F2Q_HOST_PACK"); c->host_pack = fv && fv[0] == '1'; }
     { const char *fv = getenv("F2Q_FORCE_GENERAL"); c->force_general = fv && fv[0] == '1'; }
@@ -342,6 +367,11 @@ extern "C" void f2q_destroy(f2q_ctx *c)
     if (c->slab_d) (void)hipFree(c->slab_d);
     if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
     if (c->hit_buf_d) (void)hipFree(c->hit_buf_d);
+    if (c->pt_s.streams) (void)hipFree(c->pt_s.streams);
+    if (c->pt_s.cnt) (void)hipFree(c->pt_s.cnt);
+    if (c->pt_stat_d) (void)hipFree(c->pt_stat_d);
+    if (c->pt_slab0_d) (void)hipFree(c->pt_slab0_d);
+    if (c->pt_slab1_d) (void)hipFree(c->pt_slab1_d);
     if (c->run_d) (void)hipFree(c->run_d);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -546,12 +576,85 @@ static int ec_reserve(f2q_ctx *c, uint64_t keys64, uint64_t reads, uint64_t key_
     return F2Q_OK;
 }
 
+// ---- the partitioned path (f2q_part_kernels.h) -------------------------------------------------------------------
+template <class T>
+static int pt_grow(f2q_ctx *c, T **buf, size_t &have, size_t want, bool zero)
+{
+    if (want <= have) return F2Q_OK;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; have = 0;
+    HIPC(c, hipMalloc((void **)buf, want * sizeof(T)));
+    if (zero) HIPC(c, hipMemsetAsync(*buf, 0, want * sizeof(T), c->stream));
+    have = want;
+    return F2Q_OK;
+}
+// fixed-offset Counter mode on a partitioned library: the block's tiles in chunks, each scattered and then counted
+static int launch_part(f2q_ctx *c, const PackedBlock &pb, Accum &acc, uint32_t &launches)
+{
+    const PtDesc &pt = c->lib_h.pt;
+    const uint32_t P = pt.n_parts, nf = c->lib_h.n_features;
+    const int pw = P <= 8 ? 16 : P <= 16 ? 8 : 4;                    // scatter waves per workgroup: n_parts KiB of rings each
+    // rounds of equal size, none above pt_chunk_reads (the scratch memory of a round is 8 bytes x partitions x its reads)
+    const uint32_t max_tiles = (uint32_t)std::max<uint64_t>(c->pt_chunk_reads / F2Q_TILE, 1);
+    const uint32_t n_rounds = std::max<uint32_t>(1u, (pb.n_tiles + max_tiles - 1) / max_tiles);
+    const uint32_t chunk_tiles = std::max<uint32_t>(1u, (pb.n_tiles + n_rounds - 1) / n_rounds);
+    const uint32_t grid1 = std::min<uint32_t>((uint32_t)c->n_cu, (chunk_tiles + pw - 1) / pw);
+    const uint32_t tiles_per_wg = (chunk_tiles + grid1 - 1) / grid1 + (uint32_t)pw;          // (waves take tiles round robin)
+    // entries per stream: what a workgroup can produce, in whole steps of the count pass, plus 11 x 256 bytes: the streams
+    // grow at the same pace, and at a power-of-two distance their write positions would share memory channels
+    const uint32_t cap = ((tiles_per_wg * F2Q_TILE + F2Q_PC_STEP - 1) / F2Q_PC_STEP) * F2Q_PC_STEP + F2Q_PC_STEP + 352u;
+    const uint32_t K = std::max<uint32_t>(1u, (uint32_t)c->n_cu / P), grid2 = K * P, cw = F2Q_PC_THREADS / 64;
+    if ((grid1 + K - 1) / K > 64) return fail(c, F2Q_EUNSUPPORTED, "partitioned path: more than 64 streams per counting workgroup");
+    const uint32_t n_slots1 = 2u << pt.bb1, rows = grid1 + grid2;
+    int rc;
+    if ((rc = pt_grow(c, &c->pt_s.streams, c->pt_streams_n, (size_t)grid1 * P * cap, false))) return rc;
+    if ((rc = pt_grow(c, &c->pt_s.cnt, c->pt_cnt_n, (size_t)grid1 * P, false))) return rc;
+    if ((rc = pt_grow(c, &c->pt_slab0_d, c->pt_slab0_n, (size_t)grid2 * std::max<uint32_t>(pt.max_part, 1u), true))) return rc;
+    if ((rc = pt_grow(c, &c->pt_slab1_d, c->pt_slab1_n, (size_t)n_slots1, true))) return rc;
+    if ((rc = pt_grow(c, &c->pt_stat_d, c->pt_stat_n, (size_t)rows * 8, true))) return rc;     // rows accumulate; k_part_reduce clears them
+    PartScratch ps = c->pt_s;
+    ps.cap = cap; ps.n_wg1 = grid1;
+    Accum a1 = acc, a2 = acc;
+    a1.stat_slab = c->pt_stat_d; a2.stat_slab = a1.stat_slab + (size_t)grid1 * 8;
+    const FixedGeom fg = fixed_geom(c->run_h);
+    const bool spec52 = !c->force_generic && fg.nq == 5 && fg.nb == 2 && c->run_h.thr >= 33;
+    const bool a20 = spec52 && fg.L == 20 && (fg.st & 15) == 0;
+    const bool near = c->run_h.miss > 0;
+    const size_t shmem1 = (size_t)pw * P * F2Q_PS_RING * 8 + (size_t)(pw + 1) * P * 4;
+    const size_t shmem2 = ((size_t)F2Q_LT_SLOTS + F2Q_LT_BUCKETS) * 4 + (near ? (size_t)cw * (F2Q_PC_RING * 8 + F2Q_PC_VIA * 4) : 0);
+    auto kern2 = near ? k_part_count<true> : k_part_count<false>;
+    (void)hipFuncSetAttribute((const void *)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2);
+    for (uint32_t t0 = 0; t0 < pb.n_tiles; t0 += chunk_tiles) {
+        const uint32_t t1 = std::min<uint32_t>(pb.n_tiles, t0 + chunk_tiles);
+#define F2Q_LAUNCH_PS(PW_)                                                                                             \
+        do {                                                                                                           \
+            auto k1 = a20 ? k_part_scatter<5, 2, true, PW_> : spec52 ? k_part_scatter<5, 2, false, PW_> : k_part_scatter<0, 0, false, PW_>; \
+            (void)hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem1);      \
+            hipLaunchKernelGGL(k1, dim3(grid1), dim3(64 * PW_), shmem1, c->stream, c->run_d, c->lib_d, pb, a1, ps, t0, t1); \
+        } while (0)
+        if (pw == 16) F2Q_LAUNCH_PS(16); else if (pw == 8) F2Q_LAUNCH_PS(8); else F2Q_LAUNCH_PS(4);
+#undef F2Q_LAUNCH_PS
+        HIPC(c, hipGetLastError());
+        hipLaunchKernelGGL(kern2, dim3(grid2), dim3(64 * cw), shmem2, c->stream, c->run_d, c->lib_d, a2, ps, c->pt_slab0_d, c->pt_slab1_d);
+        HIPC(c, hipGetLastError());
+        launches += 2;
+    }
+    hipLaunchKernelGGL(k_part_reduce, dim3(std::max<uint32_t>(1u, (nf + 63) / 64)), dim3(256), 0, c->stream, c->lib_d, c->pt_slab0_d, K,
+                       near ? c->pt_slab1_d : (uint32_t *)nullptr, acc.counts, c->pt_stat_d, rows, acc.stats);
+    HIPC(c, hipGetLastError());
+    launches++;
+    return F2Q_OK;
+}
+
 // ---- launching ----------------------------------------------------------------------------------
 // one set of launches over a view of a block (all of it in Counter mode, a step of it in Extract+Count mode)
 static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, Accum &acc, uint32_t &launches)
 {
+    if (pb.n_tiles) c->last_path = F2Q_PATH_NONE;
     if (pb.n_tiles && pb.planar_nw && c->plan.multi_pair) {
         // several --us/--ds pairs on the planes
+        c->last_path = F2Q_PATH_PAIRS;
         const bool lds = c->prm.mode == 0 && c->lib_h.n_features <= F2Q_HIST_MAX;
         const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * 6u);
         const size_t shmem = lds ? std::max<size_t>(4, (((size_t)c->lib_h.n_features + 1) / 2) * 4) : 4;
@@ -579,6 +682,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         // packed anchored path
         const bool ecm = c->prm.mode == 1;
         const bool lds = !ecm && c->lib_h.n_features <= F2Q_HIST_MAX;
+        c->last_path = ecm ? F2Q_PATH_EXTRACT : F2Q_PATH_ANCHOR;
         uint32_t an_mult = 4u; { const char *e = getenv("F2Q_AN_GRID"); if (e && atoi(e) > 0) an_mult = (uint32_t)atoi(e); }
         const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * an_mult);
         const size_t shmem = (size_t)F2Q_AN_WAVES * F2Q_AN_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
@@ -598,6 +702,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
         // the library in LDS (Counter mode, uniform 14..21-base library, --m <= 1, default --qsu/--qsd)
         if (!ecm && lds && sameq && !c->no_lt && c->lib_h.lt.ok && c->run_h.miss <= 1 && pb.len != nullptr) {
+            c->last_path = F2Q_PATH_ANCHOR_LDS;
             const uint32_t groups = (pb.n_tiles + F2Q_ALT_GROUPS - 1) / F2Q_ALT_GROUPS;
             const uint32_t lgrid = std::min<uint32_t>(groups, (uint32_t)c->n_cu);
             const bool near = c->run_h.miss > 0;
@@ -663,6 +768,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
     } else if (pb.n_tiles && c->prm.mode == 1) {
         const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
         const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 4u);
+        c->last_path = F2Q_PATH_EXTRACT;
         hipLaunchKernelGGL(k_extract_fixed4, dim3(grid), dim3(F2Q_V2_THREADS), 0, c->stream, c->run_d, c->ec, pb, acc, c->reads_seen);
         HIPC(c, hipGetLastError());
         launches++;
@@ -672,6 +778,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
                         c->lib_h.n_irregular == 0;
         if (c->plan.multi) {
             // several windows per read (--st a,b,...): k-part keys against the k-part features
+            c->last_path = F2Q_PATH_MULTI;
             const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * 2u);
             const size_t shmem = (size_t)F2Q_V2_WAVES * F2Q_V2_QCAP * 12 + (lds ? (size_t)c->lib_h.n_features * 4 : 0);
@@ -698,7 +805,17 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         const bool use_lt = v2 && lds && !c->no_lt && c->lib_h.lt.ok && c->lib_h.lt.len == (uint32_t)c->run_h.length &&
                             c->run_h.miss <= 1 && (uint32_t)(fgeo.qw0 + fgeo.nq) <= pb.wq && (uint32_t)(fgeo.bw0 + fgeo.nb) <= pb.wb &&
                             pb.len != nullptr;
-        if (use_lt) {
+        // a library beyond one workgroup's LDS, dealt into partitions (or F2Q_PT_PARTS set: that path whatever the size)
+        const bool use_pt = v2 && !c->no_pt && c->lib_h.pt.ok && c->lib_h.pt.len == (uint32_t)c->run_h.length && c->run_h.miss <= 1 &&
+                            (uint32_t)(fgeo.qw0 + fgeo.nq) <= pb.wq && (uint32_t)(fgeo.bw0 + fgeo.nb) <= pb.wb && pb.len != nullptr &&
+                            (c->ix.pt_force_parts > 0 || (!use_lt && (uint64_t)pb.n_tiles * F2Q_TILE >= c->pt_min_reads));
+        if (use_pt) {
+            c->last_path = F2Q_PATH_FIXED_PART;
+            int prc = launch_part(c, pb, acc, launches);
+            if (prc) return prc;
+            launches--;                                  // (the common tail below counts one)
+        } else if (use_lt) {
+            c->last_path = F2Q_PATH_FIXED_LDS;
             const uint32_t wgs = (pb.n_tiles + F2Q_LT_WAVES - 1) / F2Q_LT_WAVES;
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu);
             const bool near = c->run_h.miss > 0;
@@ -725,6 +842,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
                                c->slab_d, grid, nf_, acc.counts, c->stat_slab_d, grid, acc.stats);
             launches++;
         } else if (v2) {
+            c->last_path = F2Q_PATH_FIXED_PACKED;
             const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;
             uint32_t v2_mult = 2u; { const char *e = getenv("F2Q_V2_GRID"); if (e && atoi(e) > 0) v2_mult = (uint32_t)atoi(e); }
             const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu * v2_mult);
@@ -774,6 +892,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
                 launches++;
             }
         } else {
+            c->last_path = F2Q_PATH_FIXED_V1;
             const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * 8u);
             if (lds) {
                 size_t shmem = std::max<size_t>(4, (size_t)c->lib_h.n_features * 4);
@@ -1042,7 +1161,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t, hipEvent_
     { unsigned long long h[4]; (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(h, acc.stamp, 32, hipMemcpyDeviceToHost);
       (void)hipMemset(acc.stamp, 0, 64);
       unsigned long long tot = h[0] + h[1] + h[2] + h[3];
-      if (tot) fprintf(stderr, "[stamp] loads+fail %.1f%%  anchors %.1f%%  key/probe %.1f%%  drain %.1f%%  (%.0f cycles/wave-tile)\n",
+      if (tot) fprintf(stderr, "[stamp] phase 0 %.1f%%  1 %.1f%%  2 %.1f%%  3 %.1f%%  (%.0f clock ticks/wave-tile)\n",
                        100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot,
                        (double)tot / ((double)b->pb.n_tiles * 4)); }
 #endif
@@ -1051,7 +1170,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t, hipEvent_
         float ms = 0;
         HIPC(c, hipEventElapsedTime(&ms, k0, k1));
         t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
-        t->fast_reads = b->n_reads - b->n_general; t->launches = launches;
+        t->fast_reads = b->n_reads - b->n_general; t->launches = launches; t->path = c->last_path;
     }
     if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && !c->no_hot && !c->plan.multi_pair && (b->pb.planar_nw ? b->pb.len != nullptr : true))) {
         // (the hot-key path has looked at the counters after its last launch; what its deferred passes could still
@@ -1336,7 +1455,7 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
         rc = count_window(c, fastq + pos, take, nullptr, &used, t ? &one : nullptr);
         if (rc) return rc;
         sum.kernel_ms += one.kernel_ms; sum.reads += one.reads; sum.fast_reads += one.fast_reads;
-        sum.general_reads += one.general_reads; sum.launches += one.launches;
+        sum.general_reads += one.general_reads; sum.launches += one.launches; if (one.path) sum.path = one.path;
         if (used == 0) break;                          // no complete record left in this window
         pos += used;
         if (take < ((size_t)1 << 30)) break;           // that was the tail: what is left is a partial record
@@ -1570,7 +1689,7 @@ static int count_file_impl(f2q_ctx *c, const char *path, uint32_t rank, uint32_t
             if (mine.buf) { (void)hipStreamSynchronize(c->stream); std::vector<void *> v{mine.buf}; free_all(c, v); mine = Staged(); }   // not used after all
             if (eof) used = have;                  // trailing partial record is dropped (:392)
             sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
-            sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
+            sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches; if (one.path) sum.path = one.path;
         }
         if (!rc) { std::vector<uint8_t> rest(base + used, base + have); carry.swap(rest); }
         { std::lock_guard<std::mutex> g(mu); slot_free[pc.slot] = true; if (rc || eof) stop = true; }
@@ -1867,7 +1986,7 @@ extern "C" int f2q_count_pieces(f2q_ctx *c, const char *path, uint32_t rank, uin
                 }
             } else rc = count_window(c, base, pc.n - pc.a, nullptr, &used, &one, pc.max_rec);
             sum.kernel_ms += one.kernel_ms; sum.total_ms += one.total_ms; sum.reads += one.reads;
-            sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches;
+            sum.fast_reads += one.fast_reads; sum.general_reads += one.general_reads; sum.launches += one.launches; if (one.path) sum.path = one.path;
         }
         if (mine.buf) { (void)hipStreamSynchronize(c->stream); std::vector<void *> v{mine.buf}; free_all(c, v); }
         { std::lock_guard<std::mutex> g(mu); slot_free[pc.slot] = true; if (rc) stop = true; }

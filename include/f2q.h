@@ -91,8 +91,21 @@ typedef struct {
     uint64_t fast_reads;                 /* ... of which went through the packed fast path      */
     uint64_t general_reads;              /* ... of which went through the general path          */
     uint32_t launches;                   /* kernel launches in the call                         */
-    uint32_t reserved;
+    uint32_t path;                       /* kernel family that counted the packed tiles of the call (F2Q_PATH_*, diagnostics) */
 } f2q_timing;
+/* f2q_timing.path */
+enum {
+    F2Q_PATH_NONE = 0,                   /* no packed tiles / not recorded                        */
+    F2Q_PATH_FIXED_V1 = 1,               /* one read per lane, wide tables                        */
+    F2Q_PATH_FIXED_PACKED = 2,           /* k_count_fixed4: packed tables in L2                   */
+    F2Q_PATH_FIXED_LDS = 3,              /* k_count_fixed4_lds: the library in LDS                */
+    F2Q_PATH_FIXED_PART = 4,             /* k_part_*: a large library dealt into LDS-sized partitions */
+    F2Q_PATH_MULTI = 5,                  /* k_count_multi4                                        */
+    F2Q_PATH_ANCHOR = 6,                 /* k_count_anchor                                        */
+    F2Q_PATH_ANCHOR_LDS = 7,             /* k_count_anchor_lt                                     */
+    F2Q_PATH_PAIRS = 8,                  /* k_count_anchor_pairs                                  */
+    F2Q_PATH_EXTRACT = 9                 /* the Extract+Count kernels                             */
+};
 
 typedef struct f2q_block f2q_block;      /* a device-resident block of reads (opaque)           */
 

@@ -24,7 +24,7 @@ struct Emu {
     EcDev ec; std::vector<unsigned long long> slots, ent_off, ent_count, ent_first, ctr, k64s, k64c, k64f; std::vector<uint32_t> ent_len, arena;
     uint64_t reads_seen = 0, fast = 0, general = 0, v2_reads = 0, anchor_reads = 0;
     int use_v2 = 1, use_lt = 1;
-    uint64_t lt_reads = 0;
+    uint64_t lt_reads = 0, pt_reads = 0;
     std::string err;
 };
 
@@ -38,6 +38,9 @@ static void bind_lib(Emu *e)
     L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
     L.lt = e->ix.lt; L.lt.tags = e->ix.lt_tags.data(); L.lt.slot_of = e->ix.lt_slot_of.data();
     L.lt.feat_of = e->ix.lt_feat_of.data();
+    L.pt = e->ix.pt; L.pt.tags0 = e->ix.pt_tags0.data(); L.pt.tags1 = e->ix.pt_tags1.data(); L.pt.pstart = e->ix.pt_pstart.data();
+    L.pt.slot0_of = e->ix.pt_slot0_of.data(); L.pt.slot1_of = e->ix.pt_slot1_of.data(); L.pt.feat_of = e->ix.pt_feat_of.data();
+    L.pt.feat0_of = e->ix.pt_feat0_of.data();
     L.gk.n_groups = e->ix.n_features ? (uint32_t)e->ix.gk_groups.size() : 0u; L.gk.grp = e->ix.gk_groups.data();
     L.gk.tab = e->ix.gk_tab.data(); L.gk.ids = e->ix.gk_ids.data();
     L.gk.fw = e->ix.gk_fw.data(); L.gk.fwoff = e->ix.gk_fwoff.data();
@@ -358,6 +361,43 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                         res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
                     else if ((int)(l & 0x7FFFu) < need) res = bad[j] ? R_QFAIL : R_NONALIGNED;   // clipped window, uniform library
                     else if (bad[j]) res = R_QFAIL;
+                    else if (e->lib.pt.ok && rows_ok && (e->ix.pt_force_parts > 0 || !e->lib.lt.ok)) {
+                        // k_part_scatter + k_part_count: the entry as it travels between the passes, the partition's table 0,
+                        // the global table 1, hits by table-0 slot or (through table 1) by table-1 slot
+                        const PtDesc &pt = e->lib.pt;
+                        const uint32_t forced = (l & F2Q_LEN_FLAG) ? fixed4_flags(g, qr, j) : 0u;
+                        if (forced && (e->run.miss == 0 || (forced & (forced - 1u)) != 0u)) res = R_NONALIGNED;
+                        else {
+                            const unsigned long long ent = pt_entry(fixed4_key(g, b, j), forced, pt.len);
+                            const uint64_t key = ent & ((1ull << (2u * pt.len)) - 1ull);
+                            const uint32_t fo = (uint32_t)(ent >> (2u * pt.len)) & ((1u << pt.len) - 1u);
+                            const uint32_t p = pt_part((uint32_t)key & ((1u << pt.hb0) - 1u), pt.n_parts);
+                            LtDesc lt{}; lt.hb0 = pt.hb0; lt.hb1 = pt.hb1; lt.len = pt.len;
+                            const LtProbe q = lt_probe(lt, key, pt.bb1);
+                            const uint32_t *t0 = pt.tags0 + (size_t)p * F2Q_LT_SLOTS;
+                            U2 en[4];
+                            en[0] = U2{t0[2u * q.b[0]], t0[2u * q.b[0] + 1u]}; en[1] = U2{t0[2u * q.b[1]], t0[2u * q.b[1] + 1u]};
+                            // table 1: the first-choice bucket; the second one only where the first carries the mark (PtDesc::spill)
+                            en[2] = U2{pt.tags1[2u * q.b[2]], pt.tags1[2u * q.b[2] + 1u]}; en[3] = U2{F2Q_LT_EMPTY, F2Q_LT_EMPTY};
+                            if (!pt.spill || (en[2].x != F2Q_LT_EMPTY && (en[2].x & pt.spill))) en[3] = U2{pt.tags1[2u * q.b[3]], pt.tags1[2u * q.b[3] + 1u]};
+                            if (pt.spill && en[2].x != F2Q_LT_EMPTY) en[2].x &= ~pt.spill;
+                            if (pt.spill && en[3].x != F2Q_LT_EMPTY) en[3].x &= ~pt.spill;
+                            if (e->run.miss == 0) { en[2] = U2{F2Q_LT_EMPTY, F2Q_LT_EMPTY}; en[3] = en[2]; }
+                            // k_part_count: the exact hit from the partition's table 0 (equality with the query's own tags);
+                            // every other entry waits in the ring and is decided by lt_near1 over the eight tags
+                            const int ex = fo == 0u ? lt_exact(lt, q, en[0], en[1]) : -1;
+                            uint32_t hit = 0, hitw = 0;
+                            if (ex >= 0) { res = R_PERFECT; idx = pt.feat0_of[(size_t)p * F2Q_LT_SLOTS + (uint32_t)ex]; }
+                            else if (e->run.miss > 0 && lt_near1(lt, q, en, fo, hit, hitw) == 1u) {
+                                res = R_IMPERFECT;
+                                if (hit >> 31) {                 // k_part_reduce: the feature whose table-1 slot this is
+                                    idx = ~0u;
+                                    for (uint32_t gi = 0; gi < e->lib.n_features; gi++) if (pt.slot1_of[gi] == (hit & 0x7FFFFFFFu)) { idx = pt.feat_of[gi]; break; }
+                                } else idx = pt.feat0_of[(size_t)p * F2Q_LT_SLOTS + hit];
+                            } else res = R_NONALIGNED;
+                        }
+                        e->pt_reads++;
+                    }
                     else if (e->use_lt && e->lib.lt.ok && rows_ok) {
                         // k_count_fixed4_lds: the LDS tables decide (exact hit, else the unique feature at distance 1)
                         const LtDesc &lt = e->lib.lt;
@@ -429,6 +469,9 @@ void emu_use_v2(void *h, int on) { ((Emu *)h)->use_v2 = on; }
 void emu_use_lt(void *h, int on) { ((Emu *)h)->use_lt = on; }
 uint64_t emu_lt_reads(void *h) { return ((Emu *)h)->lt_reads; }
 int emu_lt_ok(void *h) { return (int)((Emu *)h)->ix.lt.ok; }
+void emu_pt_force(void *h, int parts) { ((Emu *)h)->ix.pt_force_parts = parts; }      // before emu_set_features
+uint64_t emu_pt_reads(void *h) { return ((Emu *)h)->pt_reads; }
+int emu_pt_parts(void *h) { return ((Emu *)h)->ix.pt.ok ? (int)((Emu *)h)->ix.pt.n_parts : 0; }
 uint64_t emu_v2_reads(void *h) { return ((Emu *)h)->v2_reads; }
 uint64_t emu_anchor_reads(void *h) { return ((Emu *)h)->anchor_reads; }
 // entries: first the byte-string table, then the occupied slots of the single-word table

@@ -47,6 +47,10 @@ def lib():
         L.emu_lt_reads.restype = C.c_uint64
         L.emu_lt_reads.argtypes = [vp]
         L.emu_lt_ok.argtypes = [vp]
+        L.emu_pt_force.argtypes = [vp, C.c_int]
+        L.emu_pt_reads.restype = C.c_uint64
+        L.emu_pt_reads.argtypes = [vp]
+        L.emu_pt_parts.argtypes = [vp]
         L.emu_anchor_reads.restype = C.c_uint64
         L.emu_anchor_reads.argtypes = [vp]
         L.emu_ec_n.restype = C.c_uint64
@@ -77,13 +81,15 @@ def read_file(path, piece=1 << 16, threads=0, out_cap=1 << 26):
 
 
 class Emu:
-    def __init__(self, features=None, v2=True, lt=True, **params):
+    def __init__(self, features=None, v2=True, lt=True, pt_parts=0, **params):
         self._p, self._keep = binding.make_params(**params)
         self._h = C.c_void_p(lib().emu_create(C.byref(self._p)))
         if not self._h:
             raise ValueError("emu_create failed")
         lib().emu_use_v2(self._h, 1 if v2 else 0)
         lib().emu_use_lt(self._h, 1 if lt else 0)
+        if pt_parts:
+            lib().emu_pt_force(self._h, pt_parts)      # partitioned tables whatever the library's size (F2Q_PT_PARTS)
         self.n = 0
         if features is not None:
             enc = [s.encode("latin-1") for s in features]
@@ -102,6 +108,14 @@ class Emu:
     def lt_reads(self):
         """reads decided by the LDS-table logic (k_count_fixed4_lds)"""
         return lib().emu_lt_reads(self._h)
+
+    def pt_reads(self):
+        """reads decided by the partitioned-table logic (k_part_scatter / k_part_count)"""
+        return lib().emu_pt_reads(self._h)
+
+    def pt_parts(self):
+        """partitions the library was dealt into (0: no partitioned tables)"""
+        return lib().emu_pt_parts(self._h)
 
     def lt_ok(self):
         """the cuckoo build of the LDS tables succeeded for the library"""

@@ -575,15 +575,19 @@ def test_full_size_config4_per_gpu(P, monkeypatch):
     with P.Counter(features=lib, **kw) as c:
         fq = bytes(c.synth_fastq(**small))
     orc = O.count_fastq_parallel(fq, 16, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
-    cs, ss, _, ts = _full(P, monkeypatch, {}, lib, small, **kw)
+    cs, ss, _, ts = _full(P, monkeypatch, {"F2Q_PT_MIN_READS": "0"}, lib, small, **kw)       # the partitioned kernels on the small block too
     assert ts["general_reads"] == 0 and ss == orc.stats() and cs == orc.counts()
+    ck, sk, _, tk = _full(P, monkeypatch, {}, lib, small, **kw)                               # (a block this small: the packed-table kernel)
+    assert tk["path"] == 2 and (ck, sk) == (cs, ss)
     sl = dict(small, n_reads=5_000_000)
     cp, sp, _, _ = _full(P, monkeypatch, {}, lib, sl, **kw)
     cg, sg, _, tg = _full(P, monkeypatch, {"F2Q_FORCE_GENERAL": "1"}, lib, sl, **kw)
     assert tg["general_reads"] == 5_000_000 and (cp, sp) == (cg, sg)
     full = dict(small, n_reads=50_000_000)
     c4, s4, _, t4 = _full(P, monkeypatch, {}, lib, full, **kw)
-    assert t4["general_reads"] == 0
+    assert t4["general_reads"] == 0 and t4["path"] == 4 and ts["path"] == 4       # the partitioned kernels (k_part_*)
+    c4b, s4b, _, t4b = _full(P, monkeypatch, {"F2Q_NO_PT": "1"}, lib, full, **kw)  # ... against the packed tables in L2
+    assert t4b["path"] == 2 and (c4b, s4b) == (c4, s4)
     assert s4[0] == 50_000_000 and s4[0] == sum(s4[1:]) and sum(c4) == s4[1] + s4[2]
     # shard-sum invariance: 8 consecutive shards of the same stream (what 8 ranks would count) add up to the whole
     with P.Counter(features=lib, **kw) as c:
@@ -816,3 +820,70 @@ def test_fuzz_kernels_vs_oracle(P):
                 assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts())), (seed, kw)
             fast += t["fast_reads"]; general += t["general_reads"]
     assert fast > 1000 and general > 1000
+
+
+PATH_FIXED_PACKED, PATH_FIXED_LDS, PATH_FIXED_PART = 2, 3, 4
+
+
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("glen,n_guides,start,rl,parts,chunk", [(20, 10000, 0, 150, 3, ""), (20, 30000, 3, 60, 0, "20000"), (21, 6000, 2, 75, 5, "7000"),
+                                                                  (17, 2000, 9, 150, 2, ""), (18, 20000, 0, 40, 0, ""), (20, 6000, 0, 150, 12, "50000"),
+                                                                  (20, 6000, 5, 150, 20, "")])
+def test_partitioned_kernels_vs_oracle(P, monkeypatch, miss, glen, n_guides, start, rl, parts, chunk):
+    """k_part_scatter / k_part_count / k_part_hist1 / k_part_reduce (a library dealt into LDS-sized partitions: BASELINE
+    config 4's path) against the oracle and against the packed-table kernel (F2Q_NO_PT=1): libraries beyond one
+    workgroup's LDS and small ones forced into 2...20 partitions (16, 8 and 4 scatter waves per workgroup), blocks
+    counted in one round and in several (F2Q_PT_CHUNK), dense mutations, N symbols, near-duplicates, clipped reads"""
+    guides = P.binding.synth_library(77 * glen + n_guides, n_guides, glen)
+    twins = []
+    for i, g in enumerate(guides[:600]):
+        p = (i * 7) % glen
+        twins.append(g[:p] + "ACGT"[("ACGT".index(g[p]) + 1 + i % 3) % 4] + g[p + 1:])
+    lib = list(dict.fromkeys(guides + twins))
+    kw = dict(miss=miss, length=glen, start=str(start))
+    spec = dict(seed=glen + miss + 9, n_reads=150000, read_len=rl, start=start, p_sub=0.35, p_rand=0.1, p_n=0.08, p_lowq=0.1)
+    if parts:
+        monkeypatch.setenv("F2Q_PT_PARTS", str(parts))
+    monkeypatch.setenv("F2Q_PT_MIN_READS", "0")                  # (blocks this small keep the packed-table kernel otherwise)
+    if chunk:
+        monkeypatch.setenv("F2Q_PT_CHUNK", chunk)
+    with P.Counter(features=lib, **kw) as c:
+        fq = bytes(c.synth_fastq(**spec))
+        fq = sprinkle_symbols(fq, 3, rate=0.01) + bytes(c.synth_fastq(**dict(spec, n_reads=300, read_len=start + glen - 2)))
+        orc = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+        for rep in range(2):                                     # twice: the slabs must come back cleared
+            c.reset()
+            _, t = c.count_block(fq, want_timing=True)
+            counts, stats = c.read_counts()
+            assert t["path"] == PATH_FIXED_PART and t["general_reads"] == 0
+            assert list(stats) == orc.stats() and list(counts) == orc.counts()
+    for k in ("F2Q_PT_PARTS", "F2Q_PT_CHUNK", "F2Q_PT_MIN_READS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("F2Q_NO_PT", "1")
+    with P.Counter(features=lib, **kw) as c:
+        _, t = c.count_block(fq, want_timing=True)
+        counts2, stats2 = c.read_counts()
+    monkeypatch.delenv("F2Q_NO_PT")
+    assert t["path"] in (PATH_FIXED_PACKED, PATH_FIXED_LDS)
+    assert list(stats2) == list(stats) and list(counts2) == list(counts)
+
+
+def test_partitioned_histogram_hand_off(P, monkeypatch):
+    """two of 100 k guides take nearly all of 30 M reads: the u16 counters of k_part_count pass 0x8000 hundreds of times
+    and two partitions receive almost every entry (streams of very different lengths); against the packed-table kernel"""
+    lib = P.binding.synth_library(0xF2A5 + 4, 100000, 20)
+    spec = dict(seed=5, n_reads=30_000_000, read_len=150, p_sub=0.05, p_rand=0.01)
+    res = []
+    for env in ({}, {"F2Q_NO_PT": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with P.Counter(features=lib, miss=1, phred=30, length=20, start="0") as c:
+            blk = c.synth_create(guides=[lib[3], lib[99999]], **spec)
+            t = c.count_resident(blk)
+            counts, stats = c.read_counts()
+            blk.free()
+        for k in env:
+            monkeypatch.delenv(k)
+        res.append((list(counts), list(stats), t["path"]))
+    assert res[0][2] == PATH_FIXED_PART and res[1][2] == PATH_FIXED_PACKED and res[0][:2] == res[1][:2]
+    assert res[0][0][3] > 10_000_000 and res[0][0][99999] > 10_000_000 and sum(res[0][0]) == res[0][1][1] + res[0][1][2]

@@ -107,6 +107,34 @@ def test_lds_tables_vs_oracle(miss, glen, n_guides, start):
     assert e2.read()[:2] == (counts, stats) and e2.lt_reads() == 0
 
 
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("glen,n_guides,start,parts", [(20, 9000, 0, 3), (20, 30000, 3, 0), (21, 6000, 2, 5), (17, 2000, 9, 2), (18, 20000, 0, 0),
+                                                        (14, 800, 5, 4)])
+def test_partitioned_tables_vs_oracle(miss, glen, n_guides, start, parts):
+    """k_part_scatter / k_part_count's per-read logic (a library dealt into partitions by half 0: table 0 per partition,
+    one table 1 over all features; a hit through table 1 counted by its table-1 slot) against the oracle -- on libraries
+    beyond one workgroup's LDS (parts = 0: the builder chooses) and on small ones forced into partitions, with the
+    same near-duplicate features, heavy mutation, N symbols and clipped windows as the LDS-table test."""
+    guides = synth.make_library(n_guides, glen, 77 * glen + n_guides)
+    twins = []
+    for i, g in enumerate(guides[:600]):
+        p = (i * 7) % glen
+        twins.append(g[:p] + "ACGT"[("ACGT".index(g[p]) + 1 + i % 3) % 4] + g[p + 1:])
+    lib = list(dict.fromkeys(guides + twins))
+    spec = synth.Spec(seed=glen + miss + 9, n_reads=6000, read_len=start + glen + 6, start=start, p_sub=0.35, p_rand=0.1, p_n=0.08, p_lowq=0.1)
+    fq = sprinkle_symbols(synth.make_fastq(spec, lib), 3, rate=0.01)
+    fq += synth.make_fastq(synth.Spec(seed=5, n_reads=50, read_len=start + glen - 2, start=start), lib)   # clipped windows
+    kw = dict(miss=miss, length=glen, start=str(start))
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    e = Emu(features=lib, pt_parts=parts, **kw)
+    assert e.pt_parts() >= max(parts, 2 if n_guides > 15000 else 1)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats() and counts == o.counts()
+    assert e.pt_reads() > 4000 and gen == 0 and e.lt_reads() == 0
+
+
 def multi_window_case(starts, length, rl, miss, n_reads=5000):
     """(library, FASTQ bytes, windows) of a seeded multi-window run: features of every part count, parts of a feature
     planted at the windows, substitutions / N, low-quality bases, reads that end inside a window"""
