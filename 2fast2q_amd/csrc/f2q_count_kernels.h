@@ -252,6 +252,13 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 st3 += (res[j] == R_NONALIGNED); st4 += (res[j] == R_QFAIL);
             }
             if (!USE_LDS) {
+                // Ordering: this 16-byte store also writes 0xFFFFFFFF into the words of the reads whose exact probe missed;
+                // the near search further down (drain) patches such a word with a 4-byte store issued by ANOTHER lane of
+                // this same wave.  Both stores belong to one wave's vector-memory queue, which the memory pipeline
+                // serves in issue order for accesses to the same address (a wave's global stores are not reordered among
+                // themselves), and the patch is always issued later in program order (the ring is drained after the
+                // tile's push), so the patch lands on top.  Pinned by test_hit_buf_patch_after_wide_store (most hits at
+                // distance 1, a library beyond the LDS histogram, against the oracle).
                 typedef uint32_t v4 __attribute__((ext_vector_type(4)));
                 v4 hv; hv.x = hid[0]; hv.y = hid[1]; hv.z = hid[2]; hv.w = hid[3];
                 *reinterpret_cast<v4 F2Q_GLOBAL *>(gpw(acc.hit_buf) + (uint64_t)tile * F2Q_TILE + 4u * lane) = hv;

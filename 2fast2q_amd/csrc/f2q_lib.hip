@@ -1724,6 +1724,10 @@ extern "C" int f2q_count_file_shard(f2q_ctx *c, const char *path, uint32_t rank,
 // rank knows the line index at which each of its pieces starts and counts the records whose first line STARTS in
 // its pieces, reading on past the piece's end only to finish its last record (f2q_count_pieces).
 struct PieceSpan { uint64_t base, size; };
+// a piece and its 1 MiB look-ahead are framed in one window, and the device framing indexes a window with 32 bits
+// (count_file_impl and f2q_count_block cap their windows at 1 GiB for the same reason)
+static const uint64_t F2Q_MAX_PIECE_BYTES = ((uint64_t)1 << 30) - ((uint64_t)2 << 20);
+static inline bool piece_bytes_ok(uint64_t piece_bytes) { return piece_bytes >= 4096 && piece_bytes <= F2Q_MAX_PIECE_BYTES; }
 static inline PieceSpan piece_span(uint64_t file_size, uint64_t piece_bytes, uint64_t k)
 {
     const uint64_t base = k * piece_bytes;
@@ -1770,7 +1774,7 @@ static int piece_map(TextSource &src, const char *path, uint64_t piece_bytes, Pi
 
 extern "C" int f2q_file_pieces(const char *path, uint64_t piece_bytes, uint64_t *n_pieces, int *shardable)
 {
-    if (!path || !n_pieces || !shardable || piece_bytes < 4096) return F2Q_EINVAL;
+    if (!path || !n_pieces || !shardable || !piece_bytes_ok(piece_bytes)) return F2Q_EINVAL;
     *n_pieces = 0; *shardable = 0;
     TextSource src; std::string err;
     if (src.open(path, err) != 0) { g_create_err = err; return F2Q_EIO; }
@@ -1782,7 +1786,7 @@ extern "C" int f2q_file_pieces(const char *path, uint64_t piece_bytes, uint64_t 
 // census[2k] = newlines in piece k, census[2k+1] = 1 if its last byte is a newline; only this rank's pieces are written
 extern "C" int f2q_census_pieces(const char *path, uint32_t rank, uint32_t world, uint64_t piece_bytes, uint64_t *census, uint64_t n_pieces)
 {
-    if (!path || !census || world == 0 || rank >= world || piece_bytes < 4096) return F2Q_EINVAL;
+    if (!path || !census || world == 0 || rank >= world || !piece_bytes_ok(piece_bytes)) return F2Q_EINVAL;
     TextSource src; std::string err;
     if (src.open(path, err) != 0) { g_create_err = err; return F2Q_EIO; }
     PieceMap pm;
@@ -1843,7 +1847,7 @@ extern "C" int f2q_census_pieces(const char *path, uint32_t rank, uint32_t world
 extern "C" int f2q_count_pieces(f2q_ctx *c, const char *path, uint32_t rank, uint32_t world, uint64_t piece_bytes,
                                 const uint64_t *census, uint64_t n_pieces, f2q_timing *t)
 {
-    if (!c || !path || !census || world == 0 || rank >= world || piece_bytes < 4096) return F2Q_EINVAL;
+    if (!c || !path || !census || world == 0 || rank >= world || !piece_bytes_ok(piece_bytes)) return F2Q_EINVAL;
     HIPC(c, hipSetDevice(c->device));
     TextSource src;
     { std::string err; if (src.open(path, err) != 0) return fail(c, F2Q_EIO, err); }

@@ -90,6 +90,13 @@ def iter_record_blocks(path, block_bytes=BLOCK_BYTES):
 
 
 PIECE_BYTES = 256 << 20
+MAX_PIECE_BYTES = (1 << 30) - (2 << 20)       # the library frames a piece + its look-ahead with 32-bit offsets (include/f2q.h)
+F2Q_EUNSUPPORTED = -8
+
+
+def _piece_bytes():
+    """F2Q_PIECE_BYTES, kept inside what the library accepts"""
+    return max(4096, min(int(os.environ.get("F2Q_PIECE_BYTES", PIECE_BYTES)), MAX_PIECE_BYTES))
 
 
 def count_file_sharded(ctx, path, w, block_bytes=BLOCK_BYTES):
@@ -97,24 +104,42 @@ def count_file_sharded(ctx, path, w, block_bytes=BLOCK_BYTES):
     if hasattr(ctx, "count_pieces"):
         # plain and BGZF files: every rank reads (and inflates) only its own pieces.  The 4-line framing is global, so the ranks first pool the
         # line counts of their pieces (one small all-reduce), then each frames its share on its own (include/f2q.h)
-        piece = int(os.environ.get("F2Q_PIECE_BYTES", PIECE_BYTES))
+        piece = _piece_bytes()
         n_pieces, ok = ctx.file_pieces(path, piece)
         if ok and n_pieces >= 1:
+            import numpy as np
             import torch
             import torch.distributed as dist
-            census = torch.from_numpy(ctx.census_pieces(path, w.rank, w.size, piece, n_pieces).astype("int64"))
+            # A rank whose share cannot be read (a BGZF member damaged past its header, a pread error) must not leave
+            # the others waiting in the all-reduce: the census carries one more element, "this rank failed", and when
+            # it comes back non-zero every rank takes the streaming path, which keeps what is readable and reports
+            # `truncated` the way the reference does (fast2q.py:405-407)
+            census_np, failed = np.zeros(2 * n_pieces, dtype=np.uint64), 0
+            try:
+                census_np = ctx.census_pieces(path, w.rank, w.size, piece, n_pieces)
+            except Exception:
+                failed = 1
+            census = torch.from_numpy(np.concatenate([census_np.astype("int64"), np.array([failed], dtype="int64")]))
             if w.backend == "nccl":
                 census = census.cuda()
             dist.all_reduce(census)
-            try:
-                ctx.count_pieces(path, w.rank, w.size, piece, census.cpu().numpy().astype("uint64"))
-                failed = 0
-            except Exception:                       # a line longer than the look-ahead behind a piece
-                failed = 1
-            flag = torch.tensor([failed], dtype=torch.int64, device=census.device)
-            dist.all_reduce(flag)
-            if int(flag.item()) == 0:
-                return False
+            if int(census[-1].item()) == 0:
+                error = None
+                try:
+                    ctx.count_pieces(path, w.rank, w.size, piece, census[:-1].cpu().numpy().astype("uint64"))
+                    failed = 0
+                except Exception as e:              # F2Q_EUNSUPPORTED: a line longer than the look-ahead behind a piece
+                    failed = 1
+                    if getattr(e, "code", None) != F2Q_EUNSUPPORTED:
+                        error = e                   # a device error, an out-of-memory, a sizing bug: not to be papered over
+                flag = torch.tensor([failed, 0 if error is None else 1], dtype=torch.int64, device=census.device)
+                dist.all_reduce(flag)               # (every rank gets here, whatever happened to it)
+                if error is not None:
+                    raise error
+                if int(flag[1].item()):
+                    raise RuntimeError("another rank failed while counting its pieces of " + str(path))
+                if int(flag[0].item()) == 0:
+                    return False
             ctx.reset()                            # somebody could not: all ranks take the streaming path below
     if hasattr(ctx, "count_file_shard"):           # the library streams, frames and deals the pieces itself
         return ctx.count_file_shard(path, w.rank, w.size)[1]

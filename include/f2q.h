@@ -150,7 +150,8 @@ int f2q_count_file(f2q_ctx *ctx, const char *path, f2q_timing *t);
 int f2q_count_file_shard(f2q_ctx *ctx, const char *path, uint32_t rank, uint32_t world, f2q_timing *t);
 
 /* The same job without any rank reading -- or inflating -- another rank's share (regular files, plain or BGZF): the
- * file is cut into pieces, piece k belongs to rank k % world.  Plain: byte ranges of piece_bytes (>= 4096).  BGZF: runs
+ * file is cut into pieces, piece k belongs to rank k % world.  Plain: byte ranges of piece_bytes (4096 ... 1 GiB - 2 MiB:
+ * a piece and its look-ahead are framed with 32-bit offsets; F2Q_EINVAL outside that range).  BGZF: runs
  * of whole members whose text adds up to at most piece_bytes (every member carries its compressed size in the header
  * and its text size in the trailer, so the cut needs no inflating); a rank inflates only its own runs -- once for the
  * census, once to count -- plus the few members behind a run that finish its last record.  The 4-line framing is

@@ -465,6 +465,7 @@ void emu_read_counts(void *h, int64_t *counts, int64_t *stats, uint64_t *fast, u
 }
 
 void emu_set_read_base(void *h, uint64_t b) { ((Emu *)h)->reads_seen = b; }
+void emu_reset(void *h) { Emu *e = (Emu *)h; std::fill(e->acc.begin(), e->acc.end(), 0ull); e->reads_seen = 0; e->fast = 0; e->general = 0; }   // f2q_reset_counts (Counter mode)
 void emu_use_v2(void *h, int on) { ((Emu *)h)->use_v2 = on; }
 void emu_use_lt(void *h, int on) { ((Emu *)h)->use_lt = on; }
 uint64_t emu_lt_reads(void *h) { return ((Emu *)h)->lt_reads; }

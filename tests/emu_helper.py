@@ -40,6 +40,7 @@ def lib():
         L.emu_read_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64)]
         L.emu_set_read_base.argtypes = [vp, C.c_uint64]
+        L.emu_reset.argtypes = [vp]
         L.emu_use_v2.argtypes = [vp, C.c_int]
         L.emu_v2_reads.restype = C.c_uint64
         L.emu_v2_reads.argtypes = [vp]
@@ -101,6 +102,10 @@ class Emu:
 
     def count_block(self, data):
         return lib().emu_count_block(self._h, data, len(data))
+
+    def reset(self):
+        """f2q_reset_counts (Counter mode): counts and the five counters back to zero"""
+        lib().emu_reset(self._h)
 
     def v2_reads(self):
         return lib().emu_v2_reads(self._h)

@@ -887,3 +887,53 @@ def test_partitioned_histogram_hand_off(P, monkeypatch):
         res.append((list(counts), list(stats), t["path"]))
     assert res[0][2] == PATH_FIXED_PART and res[1][2] == PATH_FIXED_PACKED and res[0][:2] == res[1][:2]
     assert res[0][0][3] > 10_000_000 and res[0][0][99999] > 10_000_000 and sum(res[0][0]) == res[0][1][1] + res[0][1][2]
+
+
+def test_hit_buf_patch_after_wide_store(P, monkeypatch):
+    """k_count_fixed4<USE_LDS=false> (a library beyond the LDS histogram on the packed tables, F2Q_NO_PT=1): a lane's four
+    feature indices leave as one 16-byte store that also writes "none" for the reads whose exact probe missed; a hit the
+    near search finds later is patched in by another lane of the wave.  With 70 % of the reads one substitution away
+    from their guide nearly every word is patched: any reordering of the two stores would lose hits.  Against the oracle."""
+    lib = P.binding.synth_library(4242, 30000, 20)
+    kw = dict(miss=1, phred=30, length=20, start="0")
+    spec = dict(seed=77, n_reads=400_000, read_len=60, p_sub=0.7, p_rand=0.02, p_n=0.01)
+    monkeypatch.setenv("F2Q_NO_PT", "1")
+    with P.Counter(features=lib, **kw) as c:
+        fq = bytes(c.synth_fastq(**spec))
+        orc = O.count_fastq_parallel(fq, 16, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+        _, t = c.count_block(fq, want_timing=True)
+        counts, stats = c.read_counts()
+    monkeypatch.delenv("F2Q_NO_PT")
+    assert t["path"] == PATH_FIXED_PACKED and t["general_reads"] == 0
+    assert list(stats) == orc.stats() and list(counts) == orc.counts()
+    assert stats[2] > 0.5 * stats[0]                              # most reads are imperfect hits
+
+
+@pytest.mark.parametrize("mixed", [False, True], ids=["uniform_library", "mixed_lengths"])
+@pytest.mark.parametrize("miss", [0, 1])
+def test_clipped_reads_are_never_dropped_by_the_packed_kernel(P, monkeypatch, miss, mixed):
+    """Regression test for the branch at f2q_count_kernels.h `else if ((int)(l & 0x7FFF) < need)` of k_count_fixed4: written
+    as `L < 1 || (short && !rows_ok)` hipcc 7.2 produced code that DROPPED reads (they reached no counter at all; found
+    by fuzz case 101).  A third of the reads end inside the window; with a uniform library they are decided in place
+    (rows_ok), with features of several lengths they take the byte-exact routine (R_SLOW).  Every record must reach
+    exactly one of the five counters, and counts and counters must equal the oracle's."""
+    monkeypatch.setenv("F2Q_NO_LT", "1")                      # the packed-table kernel (k_count_fixed4), not the LDS tables
+    monkeypatch.setenv("F2Q_NO_PT", "1")
+    guides = P.binding.synth_library(101, 600, 20)
+    lib = guides + ([g[:17] for g in guides[:80]] + [g[:12] for g in guides[80:120]] if mixed else [])
+    lib = list(dict.fromkeys(lib))
+    kw = dict(miss=miss, phred=30, length=20, start="4")
+    with P.Counter(features=lib, **kw) as c:
+        parts = []
+        for i, rl in enumerate([60, 21, 60, 23, 4, 60, 24, 10, 60]):          # read lengths: 24 is the first that holds the window
+            parts.append(bytes(c.synth_fastq(guides=guides, seed=50 + i, n_reads=3000, read_len=rl, start=4, p_sub=0.2, p_rand=0.05, p_n=0.02)))
+        fq = b"".join(parts)
+        n_records = fq.count(b"\n") // 4
+        orc = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+        _, t = c.count_block(fq, want_timing=True)
+        counts, stats = c.read_counts()
+    for k in ("F2Q_NO_LT", "F2Q_NO_PT"):
+        monkeypatch.delenv(k)
+    assert t["path"] == PATH_FIXED_PACKED
+    assert stats[0] == n_records == 27000 and stats[0] == sum(stats[1:])       # nothing dropped, nothing counted twice
+    assert list(stats) == orc.stats() and list(counts) == orc.counts()

@@ -56,6 +56,27 @@ def test_counter_mode_sharded(tmp_path, world, gz):
     assert sum(r["own_reads"] for r in res) == 3000
 
 
+@pytest.mark.parametrize("fault", ["census", "unsupported", "device"])
+def test_pieces_protocol_with_a_rank_that_cannot(tmp_path, fault):
+    """count_file_sharded's pieces protocol when ONE rank fails: a failed census (a BGZF member damaged past its header)
+    or a line beyond the look-ahead send every rank down the streaming path together -- nobody waits in an all-reduce
+    the failed rank never enters, and the result is the oracle's; any other error is raised on every rank instead of
+    being hidden behind a recount"""
+    guides = synth.make_library(200, 20, 31)
+    fq = synth.make_fastq(synth.Spec(seed=9, n_reads=3000, read_len=60), guides)
+    path = tmp_path / "s.fastq"
+    path.write_bytes(fq)
+    res = run_world(tmp_path, 2, {"features": guides, "params": {"miss": 1}, "path": str(path), "block_bytes": 40000,
+                                  "pieces_fault": fault})
+    if fault == "device":
+        assert all("raised" in r for r in res) and "code -4" in res[1]["raised"] and "another rank failed" in res[0]["raised"]
+        return
+    orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)], miss=1)
+    orc.count_fastq(fq)
+    for r in res:
+        assert r["stats"] == orc.stats() and r["counts"] == orc.counts()
+
+
 def test_extract_count_sharded(tmp_path):
     guides = synth.make_library(100, 20, 32)
     up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
