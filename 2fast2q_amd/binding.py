@@ -19,6 +19,7 @@ EXPORTS = (
     "f2q_count_file", "f2q_count_file_shard", "f2q_file_pieces", "f2q_census_pieces", "f2q_count_pieces", "f2q_synth_create", "f2q_block_from_fastq", "f2q_count_resident", "f2q_count_resident_queued", "f2q_queued_times", "f2q_block_info",
     "f2q_block_free", "f2q_synth_fastq", "f2q_synth_library", "f2q_reset_counts", "f2q_read_counts",
     "f2q_counts_device_ptr", "f2q_stream", "f2q_ec_size", "f2q_ec_fetch", "f2q_set_read_base", "f2q_synth_guides",
+    "f2q_text_upload", "f2q_count_text", "f2q_text_free",
 )
 
 ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "EHIP", -4: "ENOMEM", -5: "EIO", -6: "ETRUNCATED", -7: "ESTATE",
@@ -134,6 +135,9 @@ def load(path=None):
     L.f2q_set_features.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32), C.c_uint32]
     L.f2q_count_block.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Timing)]
     L.f2q_count_file.argtypes = [vp, C.c_char_p, C.POINTER(Timing)]
+    L.f2q_text_upload.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+    L.f2q_count_text.argtypes = [vp, vp, C.POINTER(C.c_size_t), C.POINTER(Timing)]
+    L.f2q_text_free.argtypes = [vp, vp]; L.f2q_text_free.restype = None
     L.f2q_count_file_shard.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(Timing)]
     L.f2q_file_pieces.argtypes = [C.c_char_p, C.c_uint64, u64p, C.POINTER(C.c_int)]
     L.f2q_census_pieces.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u64p, C.c_uint64]
@@ -174,6 +178,17 @@ def synth_library(seed, n, length):
         raise F2QError(rc, "f2q_synth_library")
     raw = buf.raw
     return [raw[i * length:(i + 1) * length].decode() for i in range(n)]
+
+
+class DeviceText:
+    """FASTQ text resident in device memory (f2q_text)"""
+    def __init__(self, counter, h):
+        self._c, self._h = counter, h
+
+    def free(self):
+        if self._h:
+            self._c._L.f2q_text_free(self._c._h, self._h)
+            self._h = None
 
 
 class Block:
@@ -266,6 +281,19 @@ class Counter:
             ptr = C.c_void_p(arr.ctypes.data)
         used, t = C.c_size_t(0), Timing()
         self._check(self._L.f2q_count_block(self._h, ptr, n, C.byref(used), C.byref(t)))
+        return (used.value, t.as_dict()) if want_timing else used.value
+
+    def text_upload(self, data):
+        """copy at most 1 GiB of FASTQ text into device memory once -> DeviceText (count_text takes it from there)"""
+        data = bytes(data)
+        h = C.c_void_p()
+        self._check(self._L.f2q_text_upload(self._h, C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(h)))
+        return DeviceText(self, h)
+
+    def count_text(self, text, want_timing=False):
+        """frame, pack and count FASTQ text that already sits in device memory; returns bytes consumed (and timing)"""
+        used, t = C.c_size_t(0), Timing()
+        self._check(self._L.f2q_count_text(self._h, text._h, C.byref(used), C.byref(t)))
         return (used.value, t.as_dict()) if want_timing else used.value
 
     def count_file(self, path):

@@ -1303,14 +1303,14 @@ static int exclusive_scan(f2q_ctx *c, const uint32_t *in, uint32_t *out, uint32_
 // 2 GiB of text per call; *consumed = bytes up to the end of the last complete record.
 // text that is already (on its way) in device memory: `buf` is the allocation (it becomes the block's), `text` the
 // 16-byte aligned start of the FASTQ bytes inside it, with room for the census padding behind them
-struct DevText { void *buf = nullptr; size_t cap = 0; uint8_t *text = nullptr; uint8_t last_byte = 0; };
+struct DevText { void *buf = nullptr; size_t cap = 0; uint8_t *text = nullptr; uint8_t last_byte = 0; bool borrowed = false; };   // borrowed: the caller keeps the allocation (f2q_text)
 
 static int block_from_text_device(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_block **out,
                                   const DevText *pre = nullptr, uint64_t max_records = ~0ull)
 {
     *out = nullptr; *consumed = 0;
     f2q_block *b = new f2q_block();
-    if (pre) b->allocs.push_back(pre->buf);
+    if (pre && !pre->borrowed) b->allocs.push_back(pre->buf);
     if (nbytes == 0) { if (pre) free_all(c, b->allocs); *out = b; return F2Q_OK; }    // an empty buffer is an empty block
     std::vector<void *> tmp;                         // scratch freed before returning
     int rc = F2Q_OK;
@@ -1470,6 +1470,56 @@ extern "C" int f2q_count_block(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, 
         *t = sum; t->total_ms = ms;
     }
     return F2Q_OK;
+}
+
+// ---- FASTQ text resident in device memory ------------------------------------------------------------------
+struct f2q_text { void *buf = nullptr; size_t cap = 0, nbytes = 0; uint8_t last = 0; };
+
+extern "C" int f2q_text_upload(f2q_ctx *c, const uint8_t *fastq, size_t nbytes, f2q_text **out)
+{
+    if (!c || !out || (!fastq && nbytes)) return F2Q_EINVAL;
+    if (nbytes > ((size_t)1 << 30)) return fail(c, F2Q_EINVAL, "f2q_text_upload: at most 1 GiB of text (the device framing indexes a text with 32 bits)");
+    HIPC(c, hipSetDevice(c->device));
+    f2q_text *t = new f2q_text();
+    const size_t n_chunks = (nbytes + F2Q_NL_CHUNK - 1) / F2Q_NL_CHUNK;
+    t->cap = n_chunks * F2Q_NL_CHUNK + 16; t->nbytes = nbytes; t->last = nbytes ? fastq[nbytes - 1] : 0;
+    hipError_t e = hipMalloc(&t->buf, t->cap);
+    if (e == hipSuccess && nbytes) e = hipMemcpyAsync(t->buf, fastq, nbytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { if (t->buf) (void)hipFree(t->buf); delete t; return fail(c, F2Q_EHIP, std::string("f2q_text_upload: ") + hipGetErrorString(e)); }
+    *out = t;
+    return F2Q_OK;
+}
+
+extern "C" int f2q_count_text(f2q_ctx *c, f2q_text *txt, size_t *consumed, f2q_timing *t)
+{
+    if (!c || !txt) return F2Q_EINVAL;
+    HIPC(c, hipSetDevice(c->device));
+    if (t) { memset(t, 0, sizeof *t); HIPC(c, hipEventRecord(c->ev_a, c->stream)); }
+    if (consumed) *consumed = 0;
+    DevText pre; pre.buf = txt->buf; pre.cap = txt->cap; pre.text = (uint8_t *)txt->buf; pre.last_byte = txt->last; pre.borrowed = true;
+    size_t used = 0;
+    f2q_timing one; memset(&one, 0, sizeof one);
+    int rc = txt->nbytes ? count_window(c, nullptr, txt->nbytes, &pre, &used, t ? &one : nullptr) : F2Q_OK;
+    if (rc) return rc;
+    if (consumed) *consumed = used;
+    if (t) {
+        hipError_t e = hipEventRecord(c->ev_b, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev_b);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev_a, c->ev_b);
+        if (e != hipSuccess) return fail(c, F2Q_EHIP, hipGetErrorString(e));
+        *t = one; t->total_ms = ms;
+    }
+    return F2Q_OK;
+}
+
+extern "C" void f2q_text_free(f2q_ctx *c, f2q_text *t)
+{
+    if (!t) return;
+    if (c) { (void)hipSetDevice(c->device); if (c->stream) (void)hipStreamSynchronize(c->stream); }
+    if (t->buf) (void)hipFree(t->buf);
+    delete t;
 }
 
 // ---- file streaming -------------------------------------------------------------------------------

@@ -53,6 +53,7 @@ WORKLOADS = {
 UP, DOWN = "GTTTAAGAGCTA", "CGTTACCAGGTT"
 B_CONTRACT = 188          # 38 B of 2-bit bases + 150 quality bytes per 150-bp read
 HBM_PEAK_GBS = 8000.0
+HBM_STREAM_COPY_GBS = 6290.0        # what a streaming copy reaches on MI355X (MI355X_MICROARCH.md: ~6.3 TB/s achievable)
 SEED = 0xBEEF
 PMC_CHILD_STEPS = 4
 
@@ -271,6 +272,23 @@ def end_to_end(pkg, c, fq, n_fq):
     for key in ("host_text_first", "host_text_to_counts"):             # second pass: the device buffers of that size exist
         c.reset(); t0 = time.perf_counter(); c.count_block(fq); c.read_counts(); dt = time.perf_counter() - t0
         out[key] = n_fq / dt / 1e6
+    # the same text already resident in HBM -> framed, packed and counted by the device: what producing the tile layout
+    # costs next to the counting kernel, without PCIe in the way (at most 1 GiB of text per f2q_text)
+    cut = fq[: min(len(fq), (1 << 30) - (1 << 20))]
+    if len(cut) < len(fq):
+        cut = cut[: cut.rfind(b"\n@r") + 1]
+    n_cut = cut.count(b"\n") // 4
+    txt = c.text_upload(cut)
+    try:
+        c.reset(); c.count_text(txt)
+        c.reset(); t0 = time.perf_counter(); _, tt = c.count_text(txt, want_timing=True); _, st = c.read_counts(); dt = time.perf_counter() - t0
+        out["device_text_to_counts"] = n_cut / dt / 1e6
+        out["device_text"] = {"reads": int(st[0]), "text_bytes": len(cut), "wall_ms": dt * 1e3, "stream_ms": tt["total_ms"],
+                              "counting_kernels_ms": tt["kernel_ms"], "text_GBps": len(cut) / dt / 1e9,
+                              "note": "FASTQ text resident in HBM -> k_nl_count .. k_pack -> counting kernels (f2q_count_text); no "
+                                      "host-to-device copy inside the timed call, three host waits for sizes"}
+    finally:
+        txt.free()
     d = tempfile.mkdtemp(prefix="f2q_bench_")
     try:
         p = os.path.join(d, "x.fastq")
@@ -321,8 +339,11 @@ def timed_steps(c, blk, steps, warmup, allreduce=None, barrier=None, sync=None):
     return dt, sum(kern) / len(kern)
 
 
-def main():
-    a = parse_args()
+def main(argv=None, engine=None):
+    """engine: None = the product (2fast2q_amd on a HIP device).  tests/test_bench_gloo.py passes a stand-in with the same
+    methods so that the N > 1 plumbing (slicing of the stream, the all-reduce per step, max-over-ranks timing, the checks,
+    rank 0's line) runs in the CPU test-suite; nothing in this file knows what the stand-in is."""
+    a = parse_args(argv)
     if a.pmc_child:
         return pmc_child(a)
     env_world = os.environ.get("WORLD_SIZE")
@@ -330,7 +351,7 @@ def main():
         # not under a launcher: start the ranks ourselves, before anything here touches the GPU
         port = os.environ.get("MASTER_PORT", "29511")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
-               "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+               "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
         raise SystemExit(subprocess.call(cmd))
     # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL writes a version banner at its
     # first collective) are sent to stderr for the rest of the run
@@ -351,11 +372,13 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the counting path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    device = local if a.dist_backend == "nccl" else local % ndev
-    torch.cuda.set_device(device)
+    device = 0
+    if engine is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the counting path has no CPU fallback")
+        ndev = torch.cuda.device_count()
+        device = local if a.dist_backend == "nccl" else local % ndev
+        torch.cuda.set_device(device)
     use_dist = world > 1 or a.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -364,7 +387,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    pkg = importlib.import_module("2fast2q_amd")
+    pkg = importlib.import_module("2fast2q_amd") if engine is None else engine
     total = w["n_reads"] * (world if scaling == "weak" else 1)        # reads of the whole job
     lo, hi = total * rank // world, total * (rank + 1) // world        # this rank's slice of the stream
     n = hi - lo
@@ -397,7 +420,8 @@ def main():
     def sync():
         if stream is not None:
             stream.synchronize()
-        torch.cuda.synchronize()
+        if engine is None:
+            torch.cuda.synchronize()
 
     dt, k_ms = timed_steps(c, blk, a.steps, a.warmup, allreduce, barrier, sync)
     if use_dist:
@@ -438,7 +462,7 @@ def main():
                        "general_path_reads_per_gpu": info["n_general"], "sharding": f"dp{world}",
                        "collective": (f"{a.dist_backend} all_reduce(int64[{w['n_guides'] + 5}]) per step" if use_dist else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_stream_copy": achieved / HBM_STREAM_COPY_GBS, "traffic": traffic,
                          "kernel": dominant, "kernel_ms": k_ms, "bytes_per_read": b_req,
                          "achieved_contract": contract, "frac_contract": contract / HBM_PEAK_GBS,
                          "bytes_per_read_contract": B_CONTRACT * a.read_len / 150.0,
@@ -451,12 +475,12 @@ def main():
                                   "leaves the rows outside the window untouched) and may therefore exceed the HBM peak")},
             "verify": verify,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if not a.no_cpu_baseline:                   # rank 0 of any world size (the other ranks wait at the closing barrier)
             base, one, prefix, fq = cpu_legs(pkg, c, w, a, guides, spec)
             out["cpu_baseline"], out["cpu_baseline_1core"] = base, one
             out["verify"]["prefix_vs_oracle"] = prefix
             assert prefix["equals_oracle"], "device result differs from the oracle on the prefix sample"
-            if not a.no_extras and not w.get("ec"):
+            if world == 1 and not a.no_extras and not w.get("ec"):
                 try:
                     out["end_to_end"] = end_to_end(pkg, c, fq, prefix["reads"])
                 except Exception as e:              # an optional leg must not take the bench line down

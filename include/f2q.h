@@ -136,6 +136,16 @@ int f2q_set_features(f2q_ctx *ctx, const char *seqs, const uint32_t *offs, uint3
  * rstrip(), trailing partial record ignored.  *consumed (optional) = bytes up to the end of the
  * last complete record so a caller can stream a file in blocks. */
 int f2q_count_block(f2q_ctx *ctx, const uint8_t *fastq, size_t nbytes, size_t *consumed, f2q_timing *t);
+/* The same for FASTQ text that is ALREADY in device memory: f2q_text_upload copies at most 1 GiB of text once;
+ * f2q_count_text frames, packs and counts it on the device (the ingest kernels + the counting kernels, no host-to-device
+ * copy in the call; accumulating like f2q_count_block, *consumed = bytes up to the end of the last complete record) and
+ * may be called any number of times.  What the tile layout costs to produce, without PCIe in the way (bench.py:
+ * end_to_end.device_text_to_counts); a producer that fills device memory itself would enter here.  The read-side half of
+ * reads_counter, fast2q.py:560-578, once the bytes are on the device. */
+typedef struct f2q_text f2q_text;
+int f2q_text_upload(f2q_ctx *ctx, const uint8_t *fastq, size_t nbytes, f2q_text **out);
+int f2q_count_text(f2q_ctx *ctx, f2q_text *text, size_t *consumed, f2q_timing *t);
+void f2q_text_free(f2q_ctx *ctx, f2q_text *text);
 /* reads_counter's file half (fast2q.py:560-578): plain or .gz FASTQ by path (gzip by content; blocked gzip --
  * BGZF -- is inflated member-parallel).  The file is streamed in pieces by a reader thread while the device
  * frames, packs and counts.  F2Q_ETRUNCATED: the archive is cut off or damaged; every complete line before the damage has

@@ -937,3 +937,31 @@ def test_clipped_reads_are_never_dropped_by_the_packed_kernel(P, monkeypatch, mi
     assert t["path"] == PATH_FIXED_PACKED
     assert stats[0] == n_records == 27000 and stats[0] == sum(stats[1:])       # nothing dropped, nothing counted twice
     assert list(stats) == orc.stats() and list(counts) == orc.counts()
+
+
+def test_device_resident_text(P):
+    """f2q_text_upload + f2q_count_text: FASTQ text already in device memory, framed / packed / counted there; equals
+    f2q_count_block on the same bytes and the oracle, accumulates over calls, reports the bytes consumed (a partial
+    record at the end stays), takes odd reads to the general path like the host entry"""
+    guides = P.binding.synth_library(5, 3000, 20)
+    kw = dict(miss=1, phred=30, length=20, start="3")
+    with P.Counter(features=guides, **kw) as c:
+        fq = sprinkle_symbols(bytes(c.synth_fastq(seed=4, n_reads=60000, read_len=70, start=3, p_sub=0.2, p_n=0.02)), 9, rate=0.004)
+        fq_tail = fq + b"@partial\nACGT\n"
+        orc = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(guides)], **kw)
+        txt = c.text_upload(fq_tail)
+        used, t = c.count_text(txt, want_timing=True)
+        counts, stats = c.read_counts()
+        assert used == len(fq) and t["reads"] == 60000 and t["total_ms"] >= t["kernel_ms"] > 0
+        assert list(stats) == orc.stats() and list(counts) == orc.counts()
+        c.count_text(txt)                                        # accumulates, and the text is still there
+        counts2, stats2 = c.read_counts()
+        assert list(stats2) == [2 * v for v in orc.stats()] and list(counts2) == [2 * v for v in orc.counts()]
+        txt.free()
+        c.reset()
+        c.count_block(fq_tail)
+        counts3, stats3 = c.read_counts()
+        assert list(stats3) == list(stats) and list(counts3) == list(counts)
+        empty = c.text_upload(b"")
+        assert c.count_text(empty) == 0
+        empty.free()
