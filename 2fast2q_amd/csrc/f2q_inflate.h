@@ -51,7 +51,7 @@ struct Crc32 {
 };
 
 struct Inflater {
-    enum Status { OUT_FULL = 0, DONE = 1, ERR = 2 };
+    enum Status { OUT_FULL = 0, DONE = 1, ERR = 2, BOUNDARY = 3 };     // BOUNDARY: stopped in front of a block header at or past stop_bit
 
     static constexpr int LT_BITS = 11, DT_BITS = 8;
     static constexpr uint32_t LT_CAP = 2048 + 2400, DT_CAP = 256 + 800;
@@ -62,7 +62,8 @@ struct Inflater {
     // 12-15 flags, 16-31 value (literal, length / distance base, sub-table start)
     uint32_t lt[LT_CAP], dt[DT_CAP];
     uint64_t bb = 0; int bc = 0;
-    const uint8_t *in = nullptr, *in_end = nullptr;
+    const uint8_t *in = nullptr, *in_end = nullptr, *in_begin = nullptr;
+    uint64_t stop_bit = ~0ull;                   // run() returns BOUNDARY in front of the first block header at a bit offset >= this (from in_begin)
     enum { S_HEADER, S_STORED, S_CODES, S_MATCH, S_DONE, S_ERR } st = S_HEADER;
     bool final_block = false;
     uint32_t stored_left = 0, m_len = 0, m_dist = 0;
@@ -71,9 +72,24 @@ struct Inflater {
 
     void reset(const uint8_t *p, size_t n)
     {
-        in = p; in_end = p + n; bb = 0; bc = 0; st = S_HEADER; final_block = false; stored_left = 0; m_len = m_dist = 0;
-        win_len = 0; total_out = 0;
+        in = p; in_end = p + n; in_begin = p; bb = 0; bc = 0; st = S_HEADER; final_block = false; stored_left = 0; m_len = m_dist = 0;
+        win_len = 0; total_out = 0; stop_bit = ~0ull;
     }
+    // start in front of the block header at bit offset `bit` of [p, p + n), with the `wn` <= 32768 bytes of text that
+    // precede it as the window (the parallel decoder of f2q_pargz.h continues a stream this way)
+    bool reset_at(const uint8_t *p, size_t n, uint64_t bit, const uint8_t *w, uint32_t wn)
+    {
+        reset(p, n);
+        if ((bit >> 3) > n) return false;
+        in = p + (bit >> 3);
+        if (bit & 7u) { if (!need((int)(bit & 7u))) return false; take((int)(bit & 7u)); }
+        if (wn > WSIZE) { w += wn - WSIZE; wn = WSIZE; }
+        if (wn) memcpy(win, w, wn);
+        win_len = wn;
+        return true;
+    }
+    // bit offset (from in_begin) of the next unread bit
+    uint64_t bit_pos() const { return (uint64_t)(in - in_begin) * 8u - (uint64_t)bc; }
     // first unread input byte once DONE (whole bytes still in the bit buffer are given back)
     const uint8_t *input_pos() const { return in - (bc >> 3); }
 
@@ -259,6 +275,7 @@ struct Inflater {
             }
             if (st == S_HEADER) {
                 if (final_block) { st = S_DONE; rc = DONE; break; }
+                if (bit_pos() >= stop_bit) { rc = BOUNDARY; break; }
                 if (!need(3)) { st = S_ERR; break; }
                 final_block = take(1) != 0;
                 const uint32_t type = take(2);

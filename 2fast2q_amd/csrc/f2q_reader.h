@@ -5,9 +5,12 @@
 //   BGZF   blocked gzip (bgzip, BCL Convert, samtools): every member carries its compressed size in a 'BC'
 //          extra field, so the members of one batch are inflated by a pool of workers, each straight into its
 //          final place in the caller's buffer; CRC32 and ISIZE of every member are checked like gzip does
-//   GZIP   anything else that starts with 1f 8b: one sequential raw inflate (zlib) on the reader thread; the CRC32 of
-//          the text, which gzread would compute on the same thread, is taken per piece by the worker pool
-//          (slices + crc32_combine), header/trailer/multi-member handling is done here
+//   GZIP   anything else that starts with 1f 8b.  Regular files are memory-mapped and a member of 8 MiB or more is
+//          decoded by the worker pool in parallel (f2q_pargz.h: block starts are searched for, chunks are decoded
+//          with an unknown window and resolved in order); small members, pipes and F2Q_GZ_PAR=0 take one sequential
+//          raw inflate on the reader thread.  The CRC32 of the text, which gzread would compute on the same thread,
+//          is taken per piece by the worker pool (slices + crc32_combine); header/trailer/multi-member handling is
+//          done here
 //
 // A BGZF file that turns into ordinary gzip half way (concatenated files) is continued as GZIP from that member.  A damaged or cut-off stream delivers the text before the damage and then
 // reports `truncated()` — the reference keeps what it counted before the damage and warns (:405-407), the harness does the same.
@@ -27,6 +30,7 @@
 #include <vector>
 
 #include "f2q_inflate.h"
+#include "f2q_pargz.h"
 
 struct TextSource {
     enum Kind { NONE, PLAIN, GZIP, BGZF };
@@ -39,6 +43,8 @@ struct TextSource {
     // regular files: the compressed bytes are memory-mapped and decoded by f2qz::Inflater (F2Q_ZLIB=1: zlib instead)
     const uint8_t *zmap = nullptr; size_t zmap_len = 0, zoff = 0;
     f2qz::Inflater *infl = nullptr;
+    f2qz::ParGunzip *par = nullptr; bool par_member = false, par_allowed = true;     // the current member is decoded by the pool
+    size_t par_min = (size_t)8 << 20;            // ... when at least this much compressed data lies ahead (F2Q_GZ_PAR_MIN_KB)
     std::vector<f2qz::Inflater *> worker_infl;   // BGZF: one decoder (55 KB of tables) per worker of the pool
     bool use_zlib = false;
     std::string path;
@@ -72,6 +78,8 @@ struct TextSource {
         close();
         path = p; n_threads = default_threads();
         { const char *z = getenv("F2Q_ZLIB"); use_zlib = z && z[0] == '1'; }
+        { const char *z = getenv("F2Q_GZ_PAR"); par_allowed = !(z && z[0] == '0'); }
+        { const char *z = getenv("F2Q_GZ_PAR_MIN_KB"); if (z && atol(z) >= 1) par_min = (size_t)atol(z) << 10; }
         fd = ::open(p, O_RDONLY);
         if (fd < 0) { err = std::string("cannot open ") + p; return -1; }
         struct stat st;
@@ -98,6 +106,7 @@ struct TextSource {
         if (zs_live) { inflateEnd(&zs); zs_live = false; }
         if (zmap) { munmap(const_cast<uint8_t *>(zmap), zmap_len); zmap = nullptr; zmap_len = 0; }
         delete infl; infl = nullptr; zoff = 0;
+        delete par; par = nullptr; par_member = false;
         for (auto *w : worker_infl) delete w;
         worker_infl.clear();
         in_member = false; zpos = zlen = 0; zeof = false; m_crc = 0; m_len = 0;
@@ -341,17 +350,22 @@ private:
                 const int h = mm_member_header();
                 if (h < 0) { bad = true; break; }
                 if (h == 0) break;
-                infl->reset(zmap + zoff, zmap_len - zoff);
+                // a member of 8 MiB or more (of the file: a member does not say how long it is) goes to the worker pool
+                par_member = par_allowed && n_threads >= 2 && zmap_len - zoff >= par_min;
+                if (par_member) { if (!par) par = new f2qz::ParGunzip(); par->start(zmap + zoff, zmap_len - zoff, n_threads); }
+                else infl->reset(zmap + zoff, zmap_len - zoff);
                 in_member = true; m_crc = 0; m_len = 0; seg = n;
             }
             size_t got = 0;
-            const f2qz::Inflater::Status r = infl->run(dst + n, dst + cap, &got);
+            const f2qz::Inflater::Status r = par_member ? par->read(dst + n, cap - n, &got) : infl->run(dst + n, dst + cap, &got);
             n += got;
             if (r == f2qz::Inflater::ERR) { bad = true; break; }
+            if (r == f2qz::Inflater::OUT_FULL && par_member) break;                // (the pool may end a piece early: its next round would not fit)
             if (r == f2qz::Inflater::DONE) {
                 in_member = false;
-                z_account(dst + seg, n - seg);
-                zoff = (size_t)(infl->input_pos() - zmap);
+                if (par_member) { m_crc = par->crc; m_len = par->total; }          // (the pool took the CRC of what it decoded)
+                else z_account(dst + seg, n - seg);
+                zoff = (size_t)((par_member ? par->input_end() : infl->input_pos()) - zmap);
                 if (zmap_len - zoff < 8) { bad = true; break; }
                 const uint8_t *t = zmap + zoff;
                 const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
@@ -360,7 +374,7 @@ private:
                 if (crc != m_crc || isz != (uint32_t)m_len) { bad = true; break; }
             }
         }
-        if (in_member) z_account(dst + seg, n - seg);
+        if (in_member && !par_member) z_account(dst + seg, n - seg);
         return n;
     }
 

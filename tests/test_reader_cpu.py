@@ -200,3 +200,86 @@ def test_cut_off_gzip_delivers_what_the_reference_reads(tmp_path):
             text, truncated, kind = read_file(str(path), piece=piece)
             assert truncated and kind == "gzip"
             assert text.count(b"\n") // 4 == c["expected"]["stats"][0], (c["level"], c["frac"], piece)
+
+
+# ---- ordinary gzip decoded by the worker pool (f2q_pargz.h) ------------------------------------------------------
+def big_text(n, seed):
+    """FASTQ-like text with varied qualities and a few bytes >= 128 (markers must carry any byte)"""
+    rng = random.Random(seed)
+    rec = []
+    for i in range(n):
+        L = rng.randint(30, 151)
+        q = "".join(rng.choice("IIIIIIII?5+#FF:,") for _ in range(L))
+        rec.append("@inst:%d:%d %d/1\n%s\n+\n%s\n" % (seed, i, rng.randint(0, 9), "".join(rng.choice("ACGT") for _ in range(L)), q))
+    b = bytearray("".join(rec).encode())
+    for _ in range(50):
+        b[rng.randrange(len(b))] = rng.choice([0x80, 0xFF, 0x00, 0xC3])
+    return bytes(b)
+
+
+@pytest.fixture(scope="module")
+def par_payload():
+    return big_text(40000, 7)
+
+
+@pytest.fixture()
+def par_env(monkeypatch):
+    monkeypatch.setenv("F2Q_GZ_PAR_MIN_KB", "16")           # members of 16 KiB and more go to the pool ...
+    monkeypatch.setenv("F2Q_GZ_CHUNK_KB", "64")             # ... in chunks of 64 KiB: many chunks and rounds on a few MB
+    return monkeypatch
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("threads", [2, 3, 8])
+def test_gzip_parallel_equals_gzip(tmp_path, par_payload, par_env, level, threads):
+    z = tmp_path / "a.fastq.gz"
+    with gzip.open(z, "wb", compresslevel=level) as f: f.write(par_payload)
+    for piece in (1 << 16, 1 << 20, 1 << 24):               # smaller than a round (staged text), and larger (straight into the piece)
+        assert read_file(z, piece, threads, out_cap=1 << 25) == (par_payload, False, "gzip")
+    par_env.setenv("F2Q_GZ_PAR", "0")                        # the sequential decoder on the same file
+    assert read_file(z, 1 << 20, threads, out_cap=1 << 25) == (par_payload, False, "gzip")
+
+
+def test_gzip_parallel_members_and_block_types(tmp_path, par_payload, par_env):
+    """several members (one of them small, one empty), stored blocks (level 0), fixed-Huffman blocks (tiny inputs with
+    Z_FIXED) and incompressible bytes between the text: the search only looks for dynamic blocks, the chunks in front
+    of a stretch without one simply run through it"""
+    third = len(par_payload) // 3
+    noise = os.urandom(300_000)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    fixed = co.compress(par_payload[:50_000]) + co.flush()
+    parts = [gzip.compress(par_payload[:third], 6), gzip.compress(b""), gzip.compress(noise, 0), fixed,
+             gzip.compress(par_payload[third:third + 2000], 9), gzip.compress(par_payload[third + 2000:] + noise + par_payload[:third], 1)]
+    want = par_payload[:third] + noise + par_payload[:50_000] + par_payload[third:] + noise + par_payload[:third]
+    z = tmp_path / "m.fastq.gz"; z.write_bytes(b"".join(parts))
+    assert gzip.open(z).read() == want
+    for threads in (2, 5):
+        assert read_file(z, 1 << 18, threads, out_cap=1 << 26) == (want, False, "gzip")
+
+
+@pytest.mark.parametrize("cut", [0.97, 0.5, 0.13])
+def test_gzip_parallel_cut_off_archive(tmp_path, par_payload, par_env, cut):
+    """a cut-off or damaged archive delivers exactly the bytes the sequential decoder delivers (every byte decoded before
+    the damage), and reports truncation"""
+    raw = gzip.compress(par_payload, 6)
+    z = tmp_path / "c.fastq.gz"; z.write_bytes(raw[: int(len(raw) * cut)])
+    got = read_file(z, 1 << 18, 4, out_cap=1 << 25)
+    par_env.setenv("F2Q_GZ_PAR", "0")
+    seq = read_file(z, 1 << 18, 4, out_cap=1 << 25)
+    assert got == seq and got[1] is True and par_payload.startswith(got[0]) and len(got[0]) > 0.9 * cut * len(par_payload) - 70000
+    par_env.delenv("F2Q_GZ_PAR")
+    # damage in the middle: a flipped byte
+    bad = bytearray(raw); bad[len(raw) // 2] ^= 0x55
+    z.write_bytes(bytes(bad))
+    got = read_file(z, 1 << 18, 4, out_cap=1 << 25)
+    par_env.setenv("F2Q_GZ_PAR", "0")
+    seq = read_file(z, 1 << 18, 4, out_cap=1 << 25)
+    assert got[1] is True and seq[1] is True and got[0] == seq[0]
+
+
+def test_gzip_parallel_wrong_crc_is_truncation(tmp_path, par_payload, par_env):
+    raw = bytearray(gzip.compress(par_payload, 6))
+    raw[-6] ^= 1                                             # the CRC-32 in the trailer
+    z = tmp_path / "w.fastq.gz"; z.write_bytes(bytes(raw))
+    got = read_file(z, 1 << 20, 4, out_cap=1 << 25)
+    assert got[0] == par_payload and got[1] is True
