@@ -24,6 +24,7 @@ GOLDEN = os.path.join(TESTS, "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a minute or more (full-size runs against the oracle); part of -m gpu, deselect with -m 'gpu and not slow'")
 
 
 def load_cases():

@@ -965,3 +965,44 @@ def test_device_resident_text(P):
         empty = c.text_upload(b"")
         assert c.count_text(empty) == 0
         empty.free()
+
+
+def _full_size_direct(P, kw, spec_extra, n_total=50_000_000, slice_reads=4_000_000, threads=16):
+    """the device result of the whole synthetic stream against the oracle run over the SAME stream, slice by slice
+    (FASTQ text of a slice from the device twin of the generator -> oracle on `threads` host threads -> summed)"""
+    lib = P.binding.synth_library(0xF2A5 + 3, 10000, 20)
+    feats = [(str(i), s) for i, s in enumerate(lib)]
+    tot_counts, tot_stats = None, None
+    with P.Counter(features=lib, **kw) as c:
+        for lo in range(0, n_total, slice_reads):
+            n = min(slice_reads, n_total - lo)
+            fq = bytes(c.synth_fastq(lo=lo, hi=lo + n, seed=0xBEEF, n_reads=n_total, read_len=150, **spec_extra))   # reads lo .. lo + n - 1 of the stream
+            orc = O.count_fastq_parallel(fq, threads, features=feats, **kw)
+            del fq
+            tot_counts = orc.counts() if tot_counts is None else [a + b for a, b in zip(tot_counts, orc.counts())]
+            tot_stats = orc.stats() if tot_stats is None else [a + b for a, b in zip(tot_stats, orc.stats())]
+        blk = c.synth_create(seed=0xBEEF, n_reads=n_total, read_len=150, **spec_extra)
+        t = c.count_resident(blk)
+        counts, stats = c.read_counts()
+        blk.free()
+    assert t["general_reads"] == 0
+    assert list(stats) == tot_stats and tot_stats[0] == n_total
+    assert list(counts) == tot_counts
+
+
+@pytest.mark.slow
+@pytest.mark.timeout(1200)
+def test_full_size_config3_direct_oracle(P):
+    """BASELINE config 3 at full size (50 M x 150 bp vs 10 k x 20 bp guides, --m 1 --ph 30): every per-feature count and
+    the five counters of the library-in-LDS kernel against the oracle over the whole stream (about a minute of host work)"""
+    _full_size_direct(P, dict(miss=1, phred=30, length=20, start="0"), {})
+
+
+@pytest.mark.slow
+@pytest.mark.timeout(1200)
+def test_full_size_config5a_direct_oracle(P):
+    """BASELINE config 5a at full size (anchored Counter mode, --us/--ds 12-mers, --msu 1 --msd 1 --m 1) against the
+    oracle over the whole stream"""
+    up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+    _full_size_direct(P, dict(miss=1, phred=30, upstream=up, downstream=down, miss_search_up=1, miss_search_down=1),
+                      dict(cassette=True, up=up, down=down, max_offset=100))
