@@ -1678,16 +1678,24 @@ F2Q_HD uint32_t plane_extract(const uint32_t (&P)[NW], int start, int L)
 {
     // every adjacent word pair is funnel-shifted by the in-word offset (the shift amount is per lane), then the word
     // index picks one of them through a 3-level select tree on its bits: NW + 4 instructions + 3 compares instead of
-    // a compare-and-select pair per word for each of the two source words.  Needs 0 <= start < 256.
-    static_assert(NW <= 8, "plane_extract: at most 8 words");
+    // a compare-and-select pair per word for each of the two source words.  Needs 0 <= start < 32 * (NW <= 8 ? 8 : 16).
+    static_assert(NW <= 16, "plane_extract: at most 16 words");
     const uint32_t sh = (uint32_t)start & 31u, wi = (uint32_t)start >> 5;
-    uint32_t V[8];
+    constexpr int NV = NW <= 8 ? 8 : 16;
+    uint32_t V[NV];
 #pragma unroll
-    for (int w = 0; w < 8; w++) V[w] = w < NW ? funnel_shr(w + 1 < NW ? P[w + 1] : 0u, P[w], sh) : 0u;
+    for (int w = 0; w < NV; w++) V[w] = w < NW ? funnel_shr(w + 1 < NW ? P[w + 1] : 0u, P[w], sh) : 0u;
     const bool b0 = wi & 1u, b1 = wi & 2u, b2 = wi & 4u;
     const uint32_t t0 = b0 ? V[1] : V[0], t1 = b0 ? V[3] : V[2], t2 = b0 ? V[5] : V[4], t3 = b0 ? V[7] : V[6];
     const uint32_t u0 = b1 ? t1 : t0, u1 = b1 ? t3 : t2;
-    const uint32_t v = b2 ? u1 : u0;
+    uint32_t v = b2 ? u1 : u0;
+    if (NV == 16) {                                        // reads of 161 .. 320 bases: one more level of the tree
+        const bool b3 = wi & 8u;
+        const uint32_t t4 = b0 ? V[NV - 7] : V[NV - 8], t5 = b0 ? V[NV - 5] : V[NV - 6], t6 = b0 ? V[NV - 3] : V[NV - 4], t7 = b0 ? V[NV - 1] : V[NV - 2];
+        const uint32_t u2 = b1 ? t5 : t4, u3 = b1 ? t7 : t6;
+        const uint32_t vh = b2 ? u3 : u2;
+        v = b3 ? vh : v;
+    }
     return L >= 32 ? v : (v & ((1u << L) - 1u));
 }
 
@@ -1827,7 +1835,7 @@ F2Q_HD uint64_t plane_key(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], in
 // host packer (f2q_host.h) and the device packer (k_pack in f2q_aux_kernels.h).
 // ---------------------------------------------------------------------------------------------
 #define F2Q_PACK_MAXLEN 512
-#define F2Q_ANCHOR_MAXLEN 160      // longest read the packed anchored kernel holds in registers (5 x 32 bases)
+#define F2Q_ANCHOR_MAXLEN 320      // longest read the packed anchored kernels hold in registers (10 x 32 bases: MiSeq 2 x 300 amplicons)
 
 struct PackPlan {
     bool fast_fixed = false;       // fixed offset, one window of 0..31 bases (Counter mode; Extract+Count: 0..29), or `multi`
@@ -1880,7 +1888,7 @@ F2Q_HD uint32_t packed_len(const PackPlan &pl, const RecT<P> &r)
 F2Q_HD void tile_geometry(const PackPlan &pl, uint32_t rmax_in, uint32_t &rmax, uint32_t &planar_nw, uint32_t &wb, uint32_t &wq)
 {
     rmax = rmax_in ? rmax_in : 1u;
-    if (pl.fast_anchor) { planar_nw = rmax <= 96u ? 3u : 5u; wb = 2u * planar_nw; wq = 8u * planar_nw; }
+    if (pl.fast_anchor) { planar_nw = rmax <= 96u ? 3u : rmax <= 160u ? 5u : 10u; wb = 2u * planar_nw; wq = 8u * planar_nw; }
     else { planar_nw = 0; wb = (rmax + 15u) / 16u; wq = (rmax + 3u) / 4u; }
 }
 

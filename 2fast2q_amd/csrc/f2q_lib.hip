@@ -668,7 +668,8 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
                                     c->stream, c->run_d, c->lib_d, c->ec, pb, acc, c->reads_seen);                     \
         } while (0)
 #define F2Q_LAUNCH_MP(NW_, KB_) do { if (sameq) F2Q_LAUNCH_MP2(NW_, KB_, true); else F2Q_LAUNCH_MP2(NW_, KB_, false); } while (0)
-        if (nw == 3 && kb == 0) F2Q_LAUNCH_MP(3, 0);
+        if (nw == 10) F2Q_LAUNCH_MP2(10, 3, false);      // reads of 161 .. 320 bases: the general instantiation (any --msu/--msd <= 7, any --qsu/--qsd)
+        else if (nw == 3 && kb == 0) F2Q_LAUNCH_MP(3, 0);
         else if (nw == 3 && kb == 1) F2Q_LAUNCH_MP(3, 1);
         else if (nw == 3) F2Q_LAUNCH_MP(3, 3);
         else if (kb == 0) F2Q_LAUNCH_MP(5, 0);
@@ -701,7 +702,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         const int nw = (int)pb.planar_nw, kb = c->plan.kb;
         const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
         // the library in LDS (Counter mode, uniform 14..21-base library, --m <= 1, default --qsu/--qsd)
-        if (!ecm && lds && sameq && !c->no_lt && c->lib_h.lt.ok && c->run_h.miss <= 1 && pb.len != nullptr) {
+        if (!ecm && lds && sameq && !c->no_lt && c->lib_h.lt.ok && c->run_h.miss <= 1 && pb.len != nullptr && nw != 10) {
             c->last_path = F2Q_PATH_ANCHOR_LDS;
             const uint32_t groups = (pb.n_tiles + F2Q_ALT_GROUPS - 1) / F2Q_ALT_GROUPS;
             const uint32_t lgrid = std::min<uint32_t>(groups, (uint32_t)c->n_cu);
@@ -748,7 +749,8 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
                                     shmem, c->stream, c->run_d, c->lib_d, c->ec, pb, acc, c->reads_seen);         \
         } while (0)
 #define F2Q_LAUNCH_AN(NW_, KB_) do { if (sameq) F2Q_LAUNCH_AN2(NW_, KB_, true); else F2Q_LAUNCH_AN2(NW_, KB_, false); } while (0)
-        if (nw == 3 && kb == 0) F2Q_LAUNCH_AN(3, 0);
+        if (nw == 10) F2Q_LAUNCH_AN2(10, 3, false);      // reads of 161 .. 320 bases: the general instantiation
+        else if (nw == 3 && kb == 0) F2Q_LAUNCH_AN(3, 0);
         else if (nw == 3 && kb == 1) F2Q_LAUNCH_AN(3, 1);
         else if (nw == 3) F2Q_LAUNCH_AN(3, 3);
         else if (kb == 0) F2Q_LAUNCH_AN(5, 0);
@@ -1074,7 +1076,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t, hipEvent_
             return v;
         };
         // anchored tiles (one pair) and fixed-window tiles take the hot-key kernels
-        const bool hot_path = b->pb.n_tiles && !c->no_hot && !c->plan.multi_pair && (b->pb.planar_nw ? b->pb.len != nullptr : true);
+        const bool hot_path = b->pb.n_tiles && !c->no_hot && !c->plan.multi_pair && (b->pb.planar_nw ? b->pb.len != nullptr && b->pb.planar_nw != 10 : true);
         if (hot_path) {
             // anchored tiles: hot keys in LDS.  The first hot_learn reads of a sample go through the same kernel with an
             // empty hot set (every key takes the table's insert); then the set is built and serves the rest of the sample.
@@ -1172,7 +1174,7 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t, hipEvent_
         t->kernel_ms = ms; t->reads = b->n_reads; t->general_reads = b->n_general;
         t->fast_reads = b->n_reads - b->n_general; t->launches = launches; t->path = c->last_path;
     }
-    if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && !c->no_hot && !c->plan.multi_pair && (b->pb.planar_nw ? b->pb.len != nullptr : true))) {
+    if (c->prm.mode == 1 && b->n_reads && !(b->pb.n_tiles && !c->no_hot && !c->plan.multi_pair && (b->pb.planar_nw ? b->pb.len != nullptr && b->pb.planar_nw != 10 : true))) {
         // (the hot-key path has looked at the counters after its last launch; what its deferred passes could still
         // report is seen by the next call that reads them)
         unsigned long long ctr[4];
@@ -2174,7 +2176,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
     SynthOut o; memset(&o, 0, sizeof o);
     o.all_general = fast ? 0 : 1;
     o.inband_n = c->plan.inband_n ? 1 : 0;
-    o.planar_nw = planar ? (R <= 96 ? 3u : 5u) : 0u;
+    o.planar_nw = planar ? (R <= 96 ? 3u : R <= 160 ? 5u : 10u) : 0u;
     const uint64_t n_tiles = (s->n_reads + F2Q_TILE - 1) / F2Q_TILE;
     const uint64_t n_slots = n_tiles * F2Q_TILE;
     // general-path capacity: everything, or the expected 'N' share with a wide margin

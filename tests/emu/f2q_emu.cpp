@@ -103,7 +103,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
     pb.bases = hp.bases.data(); pb.qual = hp.qual.data(); pb.len = hp.len.data(); pb.planar_nw = hp.planar_nw;
     const std::vector<uint32_t> &hp_index = hp.c_index;
     if (hp.planar_nw) {
-        // the anchored kernel's per-lane sequence (k_count_anchor), NW = 3 or 5, KB = plan.kb
+        // the anchored kernel's per-lane sequence (k_count_anchor), NW = 3, 5 or 10, KB = plan.kb
         auto lane_fn = [&](auto nwc, auto kbc, uint32_t t, uint32_t lane) {
             constexpr int NW = decltype(nwc)::value, KB = decltype(kbc)::value, NQW = 8 * NW;
             const uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + lane];
@@ -214,7 +214,8 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
         };
         for (uint32_t t = 0; t < hp.n_tiles; t++)
             for (uint32_t lane = 0; lane < F2Q_TILE; lane++) {
-                if (hp.planar_nw == 3 && e->plan.kb == 0) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 0>(), t, lane);
+                if (hp.planar_nw == 10) lane_fn(std::integral_constant<int, 10>(), std::integral_constant<int, 3>(), t, lane);     // reads of 161 .. 320 bases
+                else if (hp.planar_nw == 3 && e->plan.kb == 0) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 0>(), t, lane);
                 else if (hp.planar_nw == 5 && e->plan.kb == 0) lane_fn(std::integral_constant<int, 5>(), std::integral_constant<int, 0>(), t, lane);
                 else if (hp.planar_nw == 3 && e->plan.kb == 1) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 1>(), t, lane);
                 else if (hp.planar_nw == 3) lane_fn(std::integral_constant<int, 3>(), std::integral_constant<int, 3>(), t, lane);

@@ -1006,3 +1006,45 @@ def test_full_size_config5a_direct_oracle(P):
     up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
     _full_size_direct(P, dict(miss=1, phred=30, upstream=up, downstream=down, miss_search_up=1, miss_search_down=1),
                       dict(cassette=True, up=up, down=down, max_offset=100))
+
+
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("anchors,ms,rl", [("both", 1, 251), ("up", 0, 301), ("down", 2, 200), ("pairs", 1, 320)])
+def test_packed_anchor_long_reads_gpu(P, mode, anchors, ms, rl):
+    """reads of 161 .. 320 bases (MiSeq 2 x 250 / 2 x 300 amplicons) in anchored runs stay on the bit-plane kernels (ten
+    32-base plane words per read): general_reads counts only the reads beyond 320 bases; against the oracle"""
+    up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+    guides = P.binding.synth_library(77 + rl, 150, 20)
+    kw = dict(mode=mode, miss=1, length=20, miss_search_up=ms, miss_search_down=ms)
+    feats = guides
+    if anchors == "pairs":
+        kw["upstream"] = up + "," + up; kw["downstream"] = down + "," + down
+        feats = [g + ":" + g for g in guides[:100]] + guides[100:]
+    else:
+        if anchors in ("both", "up"):
+            kw["upstream"] = up
+        if anchors in ("both", "down"):
+            kw["downstream"] = down
+    with P.Counter(features=feats if mode == "C" else None, **kw) as c:
+        gen = dict(guides=guides, cassette=True, up=up, down=down)
+        fq = bytes(c.synth_fastq(seed=rl + ms, n_reads=30000, read_len=rl, max_offset=rl - 50, p_sub=0.2, p_lowq=0.1, p_n=0.0, **gen))
+        fq += bytes(c.synth_fastq(seed=3, n_reads=2000, read_len=90, max_offset=40, **gen))
+        fq += bytes(c.synth_fastq(seed=4, n_reads=300, read_len=400, max_offset=330, **gen))
+        orc = O.Oracle(features=[(str(i), s) for i, s in enumerate(feats)] if mode == "C" else None, **kw)
+        orc.count_fastq(fq)
+        _, t = c.count_block(fq, want_timing=True)
+        counts, stats = c.read_counts()
+        # (with ':' features in the library the few reads that carry an N take the byte-exact routine as well)
+        assert t["general_reads"] + t["fast_reads"] == 32300 and (t["general_reads"] == 300 if anchors != "pairs" else 300 <= t["general_reads"] < 340)
+        assert list(stats) == orc.stats()
+        if mode == "C":
+            assert list(counts) == orc.counts()
+        else:
+            assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))
+        # and device-generated long reads (the bench's generator at 250 bp)
+        c.reset()
+        blk = c.synth_create(seed=11, n_reads=50000, read_len=250, max_offset=190, p_n=0.0, **gen)
+        tt = c.count_resident(blk)
+        _, st2 = c.read_counts()
+        blk.free()
+        assert tt["general_reads"] == 0 and st2[0] == 50000

@@ -369,10 +369,45 @@ def test_packed_anchor_logic_vs_oracle(mode, anchors, ms, qs):
         assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
 
 
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("anchors,ms,rl", [("both", 1, 251), ("up", 0, 301), ("down", 2, 200), ("pairs", 1, 320)])
+def test_packed_anchor_long_reads(mode, anchors, ms, rl):
+    """reads of 161 .. 320 bases (MiSeq 2 x 250 / 2 x 300 amplicons) stay on the bit-plane path: ten 32-base plane words
+    per read (NW = 10), the cassette anywhere in the read, mixed with short reads and a few reads beyond 320 bases,
+    which take the byte-exact routine"""
+    guides = synth.make_library(150, 20, 77 + rl)
+    spec = synth.Spec(seed=rl + ms, n_reads=1500, read_len=rl, cassette=True, up=UP, down=DOWN, max_offset=rl - 50, p_sub=0.2, p_lowq=0.1, p_n=0.02)
+    fq = synth.make_fastq(spec, guides)
+    fq += synth.make_fastq(synth.Spec(seed=3, n_reads=200, read_len=90, cassette=True, up=UP, down=DOWN, max_offset=40), guides)
+    fq += synth.make_fastq(synth.Spec(seed=4, n_reads=40, read_len=400, cassette=True, up=UP, down=DOWN, max_offset=330), guides)
+    kw = dict(mode=mode, miss=1, length=20, miss_search_up=ms, miss_search_down=ms)
+    feats = guides
+    if anchors == "pairs":
+        kw["upstream"] = UP + "," + UP; kw["downstream"] = DOWN + "," + DOWN
+        feats = [g + ":" + g for g in guides[:100]] + guides[100:]
+    else:
+        if anchors in ("both", "up"):
+            kw["upstream"] = UP
+        if anchors in ("both", "down"):
+            kw["downstream"] = DOWN
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(feats)] if mode == "C" else None, **kw)
+    o.count_fastq(fq)
+    e = Emu(features=feats if mode == "C" else None, **kw)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats()
+    # only the reads beyond 320 bases leave the packed path (and, with ':' features in the library, the reads with an N)
+    assert e.anchor_reads() == fast and fast + gen == 1740 and (gen == 40 if anchors != "pairs" else 40 <= gen < 120)
+    if mode == "C":
+        assert counts == o.counts()
+    else:
+        assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
+
+
 def test_packed_anchor_short_and_ragged_reads():
     guides = synth.make_library(50, 12, 77)
     parts = []
-    for n, rl in ((300, 40), (300, 96), (300, 97), (200, 160), (100, 161), (50, 13)):
+    for n, rl in ((300, 40), (300, 96), (300, 97), (200, 160), (100, 161), (50, 13), (60, 320), (30, 321)):
         parts.append(synth.make_fastq(synth.Spec(seed=rl, n_reads=n, read_len=rl, cassette=True, up="ACGTAC", down="TTGCA",
                                                  max_offset=max(0, rl - 30)), guides))
     fq = b"".join(parts)
@@ -384,7 +419,7 @@ def test_packed_anchor_short_and_ragged_reads():
         e.count_block(fq)
         counts, stats, fast, gen = e.read()
         assert stats == o.stats() and counts == o.counts()
-        assert gen == 100              # only the 161-base reads exceed the packed kernel (reads holding an N are flagged in place)
+        assert gen == 30               # only the 321-base reads exceed the packed kernels (reads holding an N are flagged in place)
 
 
 @pytest.mark.parametrize("anchors", ["both", "up", "down"])
