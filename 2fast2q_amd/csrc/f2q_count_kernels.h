@@ -205,7 +205,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_fixed4(const RunDev
                 // and never fail, so bad[] already is the Phred test of the clipped window (:355-357); otherwise the
                 // byte-exact routine decides.  (Written as one test per line on purpose: hipcc 7.2 turned the
                 // equivalent `L < 1 || (short && !rows_ok)` form into code that dropped reads — fuzz case 101.)
-                else if ((int)(l & 0x7FFFu) < need) res[j] = rows_ok ? (bad[j] ? R_QFAIL : R_NONALIGNED) : R_SLOW;
+                else if ((int)(l & F2Q_LEN_MASK) < need) res[j] = rows_ok ? (bad[j] ? R_QFAIL : R_NONALIGNED) : R_SLOW;
                 else if (bad[j]) res[j] = R_QFAIL;
                 else {
                     res[j] = R_NEAR; key[j] = fixed4_key(g, brow, j);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_multi4(const RunDev
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     lv[j] = ((j < 2 ? len2.x : len2.y) >> (16 * (j & 1))) & 0xFFFFu;
-                    res[j] = lv[j] == F2Q_LEN_SKIP ? R_SKIP : ((int)(lv[j] & 0x7FFFu) < need) ? R_SLOW : R_NEAR;
+                    res[j] = lv[j] == F2Q_LEN_SKIP ? R_SKIP : ((int)(lv[j] & F2Q_LEN_MASK) < need) ? R_SLOW : R_NEAR;
                 }
             }
             const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS, 4) void k_count_multi4(const RunDev
                 if (res[j] == R_SLOW) {
                     unsigned long long st2[5] = {0, 0, 0, 0, 0};
                     const Accum acc2 = acc; const PackedBlock pb2 = pb;
-                    multi_slow(runp, libp, &acc2, &pb2, tile, 4u * lane + (uint32_t)j, (int)(lv[j] & 0x7FFFu), st2);
+                    multi_slow(runp, libp, &acc2, &pb2, tile, 4u * lane + (uint32_t)j, (int)(lv[j] & F2Q_LEN_MASK), st2);
 #pragma unroll
                     for (int k = 0; k < 5; k++) st[k] += st2[k];
                     res[j] = R_SKIP;                                   // counted by the routine itself
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
                 const bool live = l != F2Q_LEN_SKIP, qf = live && bad[j] != 0u;
                 // a read that ends inside the window gives a shorter key (:354); every feature is L long, so it can equal
                 // or approach none (:683); its bytes past the end are stored as 0 and never fail the Phred test
-                cand[a] = live && !qf && (int)(l & 0x7FFFu) >= need;
+                cand[a] = live && !qf && (int)(l & F2Q_LEN_MASK) >= need;
                 w_reads += (uint32_t)__popcll(__ballot(live));
                 w_qfail += (uint32_t)__popcll(__ballot(qf));
                 forced[a] = 0;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev 
             st[0]++;
             // bytes past the end of a short read are stored as 0 and never fail, so bad[] already is the clipped test
             if (bad[j]) { st[4]++; continue; }
-            const int rl = (int)(l & 0x7FFFu);
+            const int rl = (int)(l & F2Q_LEN_MASK);
             int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;             // Python slice clipping (:354)
             if (L < 0) L = 0;
             const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
@@ -760,8 +760,8 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev 
 // on a private copy of the read, rebuilt from the tile in memory so that the caller keeps nothing live for it
 __device__ __noinline__ void anchor_slow(const RunDev *run, const LibDev *lib, const EcDev *ec, const Accum *acc,
                                          const PackedBlock *pb, uint32_t tile, uint32_t slot, int r,
-                                         unsigned long long read_index, unsigned long long *st)
-{
+                                         unsigned long long read_index, unsigned long long *st, bool lower = false)
+{   // lower: the read's marks are lower-case bases (F2Q_LEN_CASE)
     uint8_t seq[F2Q_ANCHOR_MAXLEN], qual[F2Q_ANCHOR_MAXLEN];
     const uint32_t nw = pb->planar_nw;
     const auto bp = gp(pb->bases) + (uint64_t)tile * pb->wb * F2Q_TILE + slot;
@@ -771,7 +771,7 @@ __device__ __noinline__ void anchor_slow(const RunDev *run, const LibDev *lib, c
         const uint32_t lo = bp[(uint64_t)(i >> 5) * F2Q_TILE], hi = bp[(uint64_t)(nw + (i >> 5)) * F2Q_TILE];
         seq[i] = (uint8_t)"ACGT"[((lo >> (i & 31)) & 1u) | (((hi >> (i & 31)) & 1u) << 1)];
         qual[i] = (uint8_t)((qp[(uint64_t)planar_qword((uint32_t)i) * F2Q_TILE] >> (8 * planar_qbyte((uint32_t)i))) & 0xFFu);
-        if (qual[i] & 0x80u) { seq[i] = (uint8_t)'N'; qual[i] &= 0x7Fu; }      // flagged: a symbol that equals nothing
+        if (qual[i] & 0x80u) { seq[i] = lower ? (uint8_t)(seq[i] | 0x20u) : (uint8_t)'N'; qual[i] &= 0x7Fu; }      // marked: a lower-case base, or a symbol that equals nothing
     }
     general_read<const uint8_t *>(*run, *lib, *ec, *acc, seq, r, qual, r, read_index, st);
 }
@@ -866,11 +866,12 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 FLG[cw] = flagged ? flag_word8(q8) : 0u;          // non-ACGT symbols (rare reads)
             }
         }
+        const bool keyflag = flagged && !(l & F2Q_LEN_CASE);      // the marks count for the key too (lower-case bases: only for the anchors)
         __builtin_amdgcn_sched_barrier(0);
         STAMP(0);                                   // loads + fail vectors
         bool push = false; uint64_t push_key = 0; uint32_t push_forced = 0;
         if (l != F2Q_LEN_SKIP) {
-            const int r = (int)(l & 0x7FFFu);
+            const int r = (int)(l & F2Q_LEN_MASK);
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + tid;
             const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
             AnchorWin aw;
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 // Counter mode, all-ACGT library of <= 31-base features (the packed path's precondition): an empty
                 // or longer window passed its Phred test but can equal or approach no feature (:683) -> not aligned
                 st[3]++; st[0]++;
-            } else if (aw.ok == 1 && EC && (L > F2Q_EC64_MAXLEN || (flagged && L > 0 && !ec64_fits(plane_extract<NW>(FLG, aw.start, L), L)))) {
+            } else if (aw.ok == 1 && EC && (L > F2Q_EC64_MAXLEN || (keyflag && L > 0 && !ec64_fits(plane_extract<NW>(FLG, aw.start, L), L)))) {
                 // Extract+Count key the single-word table cannot hold (too long, or it spells an 'N'): decode the window
                 // and use the byte-string table
                 uint8_t kb[32 * NW];
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                     const int off = 32 * cw, n = L - off < 32 ? L - off : 32;
                     if (n > 0) {
                         const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
-                        const uint32_t fl = plane_extract<NW>(FLG, aw.start + off, n);
+                        const uint32_t fl = keyflag ? plane_extract<NW>(FLG, aw.start + off, n) : 0u;
                         for (int j = 0; j < n; j++) kb[off + j] = ((fl >> j) & 1u) ? (uint8_t)'N' : (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
                     }
                 }
@@ -903,10 +904,10 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
                 // negative-index slices (down-only anchor near the read start, negative --l): byte-exact routine
                 unsigned long long st2[5] = {0, 0, 0, 0, 0};
                 const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
-                anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st2);
+                anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st2, (l & F2Q_LEN_CASE) != 0u);
 #pragma unroll
                 for (int k = 0; k < 5; k++) st[k] += st2[k];
-            } else if (flagged && plane_extract<NW>(FLG, aw.start, L) != 0u) {
+            } else if (keyflag && plane_extract<NW>(FLG, aw.start, L) != 0u) {
                 // the window itself holds non-ACGT symbols
                 st[0]++;
                 const uint32_t forced = plane_extract<NW>(FLG, aw.start, L);
@@ -1033,15 +1034,16 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor_pairs(const Run
             if (!SAMEQ) { FU[cw] = fail_word8(q8, ah_u); FD[cw] = fail_word8(q8, ah_d); }
             FLG[cw] = flagged ? flag_word8(q8) : 0u;
         }
-        const int r = (int)(l & 0x7FFFu);
+        const int r = (int)(l & F2Q_LEN_MASK);
         const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
         uint32_t idx = 0;
         int res;
-        if constexpr (SAMEQ) res = pairs_lane<NW, KB>(run, lib, ec, kb, LO, HI, FLG, r, FW, FW, FW, gi, idx, &n_new);
-        else res = pairs_lane<NW, KB>(run, lib, ec, kb, LO, HI, FLG, r, FU, FD, FW, gi, idx, &n_new);
+        const bool keyflag = !(l & F2Q_LEN_CASE);                // (lower-case bases: marks for the anchors only)
+        if constexpr (SAMEQ) res = pairs_lane<NW, KB>(run, lib, ec, kb, LO, HI, FLG, r, FW, FW, FW, gi, idx, &n_new, keyflag);
+        else res = pairs_lane<NW, KB>(run, lib, ec, kb, LO, HI, FLG, r, FU, FD, FW, gi, idx, &n_new, keyflag);
         if (res < 0) {
             const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
-            anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st);
+            anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, tid, r, gi, st, !keyflag);
             continue;
         }
         st[0]++;
@@ -1149,7 +1151,7 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_count_anchor_lt(const RunDe
                 FLG[cw] = flagged ? flag_word8(q8) : 0u;
             }
         }
-        const int r = (int)(l & 0x7FFFu);
+        const int r = (int)(l & F2Q_LEN_MASK);
         AnchorWin aw;
         if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FW, FW, FW);
         else aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FU, FD, FW);
@@ -1163,10 +1165,10 @@ __global__ __launch_bounds__(F2Q_ALT_THREADS) void k_count_anchor_lt(const RunDe
         if (slow) {
             // negative-index slices (down-only anchor near the read start, negative --l): byte-exact routine
             const EcDev ec2{}; const Accum acc2 = acc; const PackedBlock pb2 = pb;
-            anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, slot_in_tile, r, 0ull, st_slow);
+            anchor_slow(runp, libp, &ec2, &acc2, &pb2, tile, slot_in_tile, r, 0ull, st_slow, (l & F2Q_LEN_CASE) != 0u);
         }
         const int ws = cand ? aw.start : 0;
-        const uint32_t forced = (cand && flagged) ? plane_extract<NW>(FLG, ws, flen) : 0u;
+        const uint32_t forced = (cand && flagged && !(l & F2Q_LEN_CASE)) ? plane_extract<NW>(FLG, ws, flen) : 0u;   // (lower-case bases: marks for the anchors only)
         const LtProbe q = lt_probe(lt, plane_key<NW>(p.lo, p.hi, ws, flen));
         U2 e[4];
 #pragma unroll
@@ -1330,7 +1332,7 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
                 FLG[cw] = flagged ? flag_word8(q8) : 0u;
             }
         }
-        const int r = (int)(l & 0x7FFFu);
+        const int r = (int)(l & F2Q_LEN_MASK);
         AnchorWin aw;
         if constexpr (SAMEQ) aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FW, FW, FW);
         else aw = anchor_window<NW, KB, KB>(run, p.lo, p.hi, FLG, r, FU, FD, FW);
@@ -1340,7 +1342,8 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
         const bool slow = live && aw.ok == 2;                   // negative-index slices: byte-exact routine
         // the key's single-word form; a window that has none (too long, too many 'N's) is set aside for the byte-string table
         const int wl0 = (pass && L >= 0 && L <= F2Q_EC64_MAXLEN) ? L : 0, ws0 = (pass && L >= 0 && L <= F2Q_EC64_MAXLEN) ? aw.start : 0;
-        const uint32_t nmask = (flagged && wl0 > 0) ? plane_extract<NW>(FLG, ws0, wl0) : 0u;
+        const bool keyflag = flagged && !(l & F2Q_LEN_CASE);    // (lower-case bases: marks for the anchors only, plain bases in the key)
+        const uint32_t nmask = (keyflag && wl0 > 0) ? plane_extract<NW>(FLG, ws0, wl0) : 0u;
         unsigned long long k = 0;
         const bool has_word = ec64_word(plane_key<NW>(p.lo, p.hi, ws0, wl0), nmask, wl0, k) && pass && L <= F2Q_EC64_MAXLEN;
         const bool later = slow || (pass && !has_word);
@@ -1351,7 +1354,7 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
         const uint64_t slot = (uint64_t)tile * F2Q_TILE + slot_in_tile;
         const unsigned long long lm = __ballot(later);
         if (lm) {
-            set_aside(lm, later, defer_entry(slot_base + slot, slow, aw.start, L) | (flagged ? F2Q_DEFER_FLAGS : 0ull));
+            set_aside(lm, later, defer_entry(slot_base + slot, slow, aw.start, L) | (keyflag ? F2Q_DEFER_FLAGS : 0ull));
             const unsigned long long sm = __ballot(slow);
             if (sm && lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(sm));
         }
@@ -1375,7 +1378,7 @@ __global__ __launch_bounds__(F2Q_HOT_THREADS) void k_extract_anchor_hot(const Ru
         }
         const unsigned long long fm = __ballot(full);
         if (fm) {                                               // the table is (nearly) full: decided after it has grown
-            set_aside(fm, full, defer_entry(slot_base + slot, true, aw.start, L) | (flagged ? F2Q_DEFER_FLAGS : 0ull));
+            set_aside(fm, full, defer_entry(slot_base + slot, true, aw.start, L) | (keyflag ? F2Q_DEFER_FLAGS : 0ull));
             if (lane == 0) ec_fetch_add(ec.ctr + F2Q_CTR_ASIDE_SLOW, (unsigned long long)__popcll(fm));
             w_reads -= (uint32_t)__popcll(fm); w_pass -= (uint32_t)__popcll(fm);
         }
@@ -1511,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_ec_deferred_slow(const RunDev *__restri
         const uint32_t l = gp(pb.len)[slot];
         const unsigned long long gi = read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot);
         const EcDev ec2 = ec; const Accum acc2 = acc; const PackedBlock pb2 = pb;
-        anchor_slow(runp, libp, &ec2, &acc2, &pb2, (uint32_t)(slot / F2Q_TILE), (uint32_t)(slot % F2Q_TILE), (int)(l & 0x7FFFu), gi, st);
+        anchor_slow(runp, libp, &ec2, &acc2, &pb2, (uint32_t)(slot / F2Q_TILE), (uint32_t)(slot % F2Q_TILE), (int)(l & F2Q_LEN_MASK), gi, st, (l & F2Q_LEN_CASE) != 0u);
     }
     __shared__ unsigned long long st_lds[8];
     flush_stats(acc, st, st_lds, nullptr);
@@ -1584,7 +1587,7 @@ __global__ __launch_bounds__(F2Q_FH_THREADS) void k_extract_fixed4_hot(const Run
             const bool live = l != F2Q_LEN_SKIP;
             ins[j] = live && !bad[j];
             st[0] += live; st[4] += live && bad[j];
-            const int rl = (int)(l & 0x7FFFu);
+            const int rl = (int)(l & F2Q_LEN_MASK);
             int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;             // Python slice clipping (:354)
             if (L < 0) L = 0;
             const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
@@ -1662,7 +1665,7 @@ __global__ __launch_bounds__(256) void k_ec_deferred_fixed(const RunDev *__restr
             brow[r] = ld_u4<false>(bp + (uint64_t)row * F2Q_TILE);
         }
         const uint32_t l = pb.len ? gp(pb.len)[slot] : pb.rmax;
-        const int rl = (int)(l & 0x7FFFu);
+        const int rl = (int)(l & F2Q_LEN_MASK);
         int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;
         if (L < 0) L = 0;
         const uint64_t key = fixed4_key(g, brow, (int)j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));

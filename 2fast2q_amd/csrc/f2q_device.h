@@ -24,6 +24,10 @@
 #define F2Q_TILE 256               // reads per packed tile (= threads per workgroup)
 #define F2Q_LEN_SKIP 0xFFFFu       // len-plane marker: slot handled by the general path
 #define F2Q_LEN_FLAG 0x8000u       // len-plane bit: the window holds non-ACGT symbols, marked by bit 7 of their quality bytes
+#define F2Q_LEN_CASE 0x4000u       // ... (anchored runs, with F2Q_LEN_FLAG) the marked bases are LOWER-CASE ACGT, nothing else: they can match no
+                                   // anchor symbol (the anchor search is case-sensitive, fast2q.py:337) but the window is upper-cased
+                                   // (:354), so for the KEY they are ordinary bases (their codes are stored) and the marks are ignored
+#define F2Q_LEN_MASK 0x3FFFu       // the read length in a len-plane entry
 
 namespace f2q {
 
@@ -982,7 +986,7 @@ F2Q_HD int fixed_lane(const RunDev &run, const LibDev &lib, const PackedBlock &p
         uint32_t l = gp(pb.len)[(uint64_t)tile * F2Q_TILE + lane];
         if (l == F2Q_LEN_SKIP) return 0;
         flagged = (l & F2Q_LEN_FLAG) != 0;
-        rlen = (int)(l & 0x7FFFu);
+        rlen = (int)(l & F2Q_LEN_MASK);
     }
     const int st = run.start[0];
     int a = st < rlen ? st : rlen;
@@ -1796,8 +1800,8 @@ template <int NW, int KB>
 F2Q_HD int pairs_lane(const RunDev &run, const LibDev &lib, const EcDev &ec, uint8_t *kb,
                       const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW], int r,
                       const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW],
-                      unsigned long long read_index, uint32_t &idx, uint32_t *n_new)
-{
+                      unsigned long long read_index, uint32_t &idx, uint32_t *n_new, bool keyflag = true)
+{   // keyflag = false: the marks of FLG are lower-case bases (F2Q_LEN_CASE): mismatches for the anchors, plain bases in the key
     int klen = 0, nparts = 0;
     for (int i = 0; i < run.n_iter; i++) {
         const AnchorWin aw = anchor_window_pair<NW, KB, KB>(run, run.up_len[i], run.down_len[i], run.mp_up_pos[i], run.mp_down_pos[i],
@@ -1810,7 +1814,7 @@ F2Q_HD int pairs_lane(const RunDev &run, const LibDev &lib, const EcDev &ec, uin
         for (int off = 0; off < L; off += 32) {
             const int n = L - off < 32 ? L - off : 32;
             const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
-            const uint32_t fl = plane_extract<NW>(FLG, aw.start + off, n);
+            const uint32_t fl = keyflag ? plane_extract<NW>(FLG, aw.start + off, n) : 0u;
             for (int j = 0; j < n; j++)
                 kb[klen++] = ((fl >> j) & 1u) ? (uint8_t)'N' : (uint8_t)(0x54474341u >> (8u * (((lo >> j) & 1u) | (((hi >> j) & 1u) << 1))));
         }
@@ -1854,18 +1858,23 @@ struct RecT { P seq; P qual; uint32_t len, qlen; };
 
 // Can this read go through a packed fast path?  The planes cannot carry a quality line of another length or
 // quality bytes >= 128 (bit 7 is the flag bit and the Phred SWAR test relies on 7-bit bytes); non-ACGT symbols
-// only as flag bits (all-ACGT library); anchored runs no lower case (the anchor search is case-sensitive, :337).
+// only as flag bits (all-ACGT library); anchored runs carry lower-case bases as marked bases (F2Q_LEN_CASE), but not
+// next to non-ACGT symbols in the same read.
 template <class P>
 F2Q_HD bool read_is_clean(const PackPlan &pl, const RecT<P> &r)
 {
     if (pl.fast_anchor) {
         if (r.qlen != r.len || r.len > F2Q_ANCHOR_MAXLEN) return false;
+        bool lower = false, odd = false;
         for (uint32_t j = 0; j < r.len; j++) {
             if (r.qual[j] & 0x80) return false;
             const uint8_t c = r.seq[j];
-            if (base_code(c) > 3u && (!pl.inband_n || c == 'a' || c == 'c' || c == 'g' || c == 't' || (pl.n_only && c != 'N'))) return false;
+            if (base_code(c) > 3u) {
+                if (c == 'a' || c == 'c' || c == 'g' || c == 't') lower = true;          // marked; its code is stored (F2Q_LEN_CASE)
+                else { if (!pl.inband_n || (pl.n_only && c != 'N')) return false; odd = true; }
+            }
         }
-        return true;
+        return !(lower && odd);                            // one kind of mark per read: both kinds take the byte-exact routine
     }
     if (!pl.fast_fixed) return false;
     if (r.qlen != r.len) return false;
@@ -1898,13 +1907,17 @@ F2Q_HD void pack_read(const PackPlan &pl, const RecT<P> &r, uint32_t planar_nw, 
 {
     const uint32_t l = packed_len(pl, r);
     const uint32_t from = pl.fast_anchor ? 0u : (uint32_t)pl.from;
-    bool flagged = false;
+    bool flagged = false, lower = false;
     if (planar_nw) {
         for (uint32_t w = 0; w * 32 < l; w++) {
             uint32_t lo = 0, hi = 0;
             for (uint32_t j = 0; j < 32 && w * 32 + j < l; j++) {
                 uint32_t c = base_code(r.seq[w * 32 + j]);
-                if (c > 3u) { c = 0; flagged = true; }
+                if (c > 3u) {
+                    flagged = true;
+                    c = base_code(up8(r.seq[w * 32 + j]));          // a lower-case base keeps its code (the key is upper-cased) ...
+                    if (c > 3u) c = 0; else lower = true;          // ... anything else is stored as 'A'
+                }
                 lo |= (c & 1u) << j; hi |= ((c >> 1) & 1u) << j;
             }
             sink.base(w, lo); sink.base(planar_nw + w, hi);
@@ -1934,7 +1947,7 @@ F2Q_HD void pack_read(const PackPlan &pl, const RecT<P> &r, uint32_t planar_nw, 
         }
         sink.qual(w, v);
     }
-    sink.len(l | (flagged ? F2Q_LEN_FLAG : 0u));
+    sink.len(l | (flagged ? F2Q_LEN_FLAG : 0u) | (lower ? F2Q_LEN_CASE : 0u));      // (read_is_clean: never both kinds of marks)
 }
 
 } // namespace f2q

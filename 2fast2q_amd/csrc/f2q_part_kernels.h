@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * PW) void k_part_scatter(const RunDev *__restri
             const uint32_t l = ((j < 2 ? r.len01 : r.len23) >> (16 * (j & 1))) & 0xFFFFu;
             const bool live = l != F2Q_LEN_SKIP, qf = live && bad[j] != 0u;
             // a read that ends inside the window can equal or approach no feature (every feature is L long, :683)
-            bool cand = live && !qf && (int)(l & 0x7FFFu) >= need;
+            bool cand = live && !qf && (int)(l & F2Q_LEN_MASK) >= need;
             uint32_t forced = 0;
             if ((l & F2Q_LEN_FLAG) && cand) {                       // non-ACGT symbols in the window (rare): forced mismatches
                 forced = fixed4_flags(g, r.q, j);

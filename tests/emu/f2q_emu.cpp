@@ -113,8 +113,9 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             const uint32_t *qp = pb.qual + (uint64_t)t * pb.wq * F2Q_TILE + lane;
             for (int w = 0; w < NW; w++) { LO[w] = bp[(uint64_t)w * F2Q_TILE]; HI[w] = bp[(uint64_t)(NW + w) * F2Q_TILE]; }
             for (int i = 0; i < NQW; i++) Q[i] = qp[(uint64_t)((uint32_t)i < pb.wq ? i : pb.wq - 1) * F2Q_TILE];
-            const int r = (int)(l & 0x7FFFu);
+            const int r = (int)(l & F2Q_LEN_MASK);
             const bool flagged = (l & F2Q_LEN_FLAG) != 0;
+            const bool lower = (l & F2Q_LEN_CASE) != 0, keyflag = flagged && !lower;   // lower-case bases: marks for the anchors only
             const unsigned long long gi = e->reads_seen + hp_index[(uint64_t)t * F2Q_TILE + lane];
             uint32_t FW[NW], FU[NW], FD[NW], FLG[NW];
             for (int cw = 0; cw < NW; cw++) {
@@ -129,13 +130,13 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                 // k_count_anchor_pairs: every pair on the same planes, the joined key matched as a string
                 uint32_t idx = 0;
                 uint8_t kb[F2Q_PAIRS_KEYMAX];
-                const int res = pairs_lane<NW, KB>(e->run, e->lib, e->ec, kb, LO, HI, FLG, r, FU, FD, FW, gi, idx, nullptr);
+                const int res = pairs_lane<NW, KB>(e->run, e->lib, e->ec, kb, LO, HI, FLG, r, FU, FD, FW, gi, idx, nullptr, !lower);
                 if (res < 0) {
                     uint8_t sq[F2Q_ANCHOR_MAXLEN], ql[F2Q_ANCHOR_MAXLEN];
                     for (int i = 0; i < r; i++) {
                         sq[i] = (uint8_t)"ACGT"[((LO[i >> 5] >> (i & 31)) & 1u) | (((HI[i >> 5] >> (i & 31)) & 1u) << 1)];
                         ql[i] = (uint8_t)((Q[planar_qword((uint32_t)i)] >> (8 * planar_qbyte((uint32_t)i))) & 0xFFu);
-                        if (ql[i] & 0x80u) { sq[i] = (uint8_t)'N'; ql[i] &= 0x7Fu; }
+                        if (ql[i] & 0x80u) { sq[i] = lower ? (uint8_t)(sq[i] | 0x20u) : (uint8_t)'N'; ql[i] &= 0x7Fu; }
                     }
                     general_read<const uint8_t *>(e->run, e->lib, e->ec, acc, sq, r, ql, r, gi, acc.stats);
                     return;
@@ -150,13 +151,13 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             const bool ecm = e->run.mode == 1;
             if (aw.ok == 0) { acc.stats[4]++; acc.stats[0]++; }
             else if (aw.ok == 1 && !ecm && (L < 1 || L > F2Q_REG_MAXLEN)) { acc.stats[3]++; acc.stats[0]++; }
-            else if (aw.ok == 1 && ecm && (L > F2Q_EC64_MAXLEN || (flagged && L > 0 && !ec64_fits(plane_extract<NW>(FLG, aw.start, L), L)))) {
+            else if (aw.ok == 1 && ecm && (L > F2Q_EC64_MAXLEN || (keyflag && L > 0 && !ec64_fits(plane_extract<NW>(FLG, aw.start, L), L)))) {
                 uint8_t kb[32 * NW];
                 for (int cw = 0; cw < NW; cw++) {
                     const int off = 32 * cw, n = L - off < 32 ? L - off : 32;
                     if (n > 0) {
                         const uint32_t lo = plane_extract<NW>(LO, aw.start + off, n), hi = plane_extract<NW>(HI, aw.start + off, n);
-                        const uint32_t fl = plane_extract<NW>(FLG, aw.start + off, n);
+                        const uint32_t fl = keyflag ? plane_extract<NW>(FLG, aw.start + off, n) : 0u;
                         for (int j = 0; j < n; j++) kb[off + j] = ((fl >> j) & 1u) ? (uint8_t)'N' : (uint8_t)"ACGT"[((lo >> j) & 1u) | (((hi >> j) & 1u) << 1)];
                     }
                 }
@@ -169,10 +170,10 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                 for (int i = 0; i < r; i++) {
                     sq[i] = (uint8_t)"ACGT"[((LO[i >> 5] >> (i & 31)) & 1u) | (((HI[i >> 5] >> (i & 31)) & 1u) << 1)];
                     ql[i] = (uint8_t)((Q[planar_qword((uint32_t)i)] >> (8 * planar_qbyte((uint32_t)i))) & 0xFFu);
-                    if (ql[i] & 0x80u) { sq[i] = (uint8_t)'N'; ql[i] &= 0x7Fu; }
+                    if (ql[i] & 0x80u) { sq[i] = lower ? (uint8_t)(sq[i] | 0x20u) : (uint8_t)'N'; ql[i] &= 0x7Fu; }
                 }
                 general_read<const uint8_t *>(e->run, e->lib, e->ec, acc, sq, r, ql, r, gi, acc.stats);
-            } else if (flagged && plane_extract<NW>(FLG, aw.start, L) != 0u) {
+            } else if (keyflag && plane_extract<NW>(FLG, aw.start, L) != 0u) {
                 acc.stats[0]++;
                 const uint32_t forced = plane_extract<NW>(FLG, aw.start, L);
                 if (ecm) {
@@ -251,7 +252,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     if (l == F2Q_LEN_SKIP) continue;
                     acc.stats[0]++; e->v2_reads++;
                     if (bad[j]) { acc.stats[4]++; continue; }
-                    const int rl = (int)(l & 0x7FFFu);
+                    const int rl = (int)(l & F2Q_LEN_MASK);
                     int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;
                     if (L < 0) L = 0;
                     const uint64_t key = fixed4_key(g, b, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
@@ -271,7 +272,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                 uint64_t key[4] = {0, 0, 0, 0}; uint32_t forced[4] = {0, 0, 0, 0}, npart[4] = {0, 0, 0, 0}, lv[4]; int res[4];
                 for (int j = 0; j < 4; j++) {
                     lv[j] = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
-                    res[j] = lv[j] == F2Q_LEN_SKIP ? R_SKIP : ((int)(lv[j] & 0x7FFFu) < e->plan.need) ? R_SLOW : R_NEAR;
+                    res[j] = lv[j] == F2Q_LEN_SKIP ? R_SKIP : ((int)(lv[j] & F2Q_LEN_MASK) < e->plan.need) ? R_SLOW : R_NEAR;
                 }
                 for (int w = 0; w < W; w++) {
                     const FixedGeom g = fixed_geom_of(e->run, w);
@@ -300,7 +301,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     if (res[j] == R_SKIP) continue;
                     e->v2_reads++;
                     if (res[j] == R_SLOW) {
-                        const uint32_t slot = 4 * lane + j; const int r = (int)(lv[j] & 0x7FFFu);
+                        const uint32_t slot = 4 * lane + j; const int r = (int)(lv[j] & F2Q_LEN_MASK);
                         uint8_t sq[F2Q_ANCHOR_MAXLEN], ql[F2Q_ANCHOR_MAXLEN];
                         const uint32_t *bps = pb.bases + ((uint64_t)t * pb.wb) * F2Q_TILE + slot, *qps = pb.qual + ((uint64_t)t * pb.wq) * F2Q_TILE + slot;
                         for (int i = 0; i < r; i++) {
@@ -358,9 +359,9 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
                     int res; uint32_t idx = 0;
                     if (l == F2Q_LEN_SKIP) res = R_SKIP;
-                    else if (g.L < 1 || ((int)(l & 0x7FFFu) < need && !rows_ok))
+                    else if (g.L < 1 || ((int)(l & F2Q_LEN_MASK) < need && !rows_ok))
                         res = fixed_lane(e->run, e->lib, pb, t, 4 * lane + j, idx);
-                    else if ((int)(l & 0x7FFFu) < need) res = bad[j] ? R_QFAIL : R_NONALIGNED;   // clipped window, uniform library
+                    else if ((int)(l & F2Q_LEN_MASK) < need) res = bad[j] ? R_QFAIL : R_NONALIGNED;   // clipped window, uniform library
                     else if (bad[j]) res = R_QFAIL;
                     else if (e->lib.pt.ok && rows_ok && (e->ix.pt_force_parts > 0 || !e->lib.lt.ok)) {
                         // k_part_scatter + k_part_count: the entry as it travels between the passes, the partition's table 0,

@@ -1048,3 +1048,38 @@ def test_packed_anchor_long_reads_gpu(P, mode, anchors, ms, rl):
         _, st2 = c.read_counts()
         blk.free()
         assert tt["general_reads"] == 0 and st2[0] == 50000
+
+
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("anchors,ms", [("both", 1), ("up", 0), ("down", 2), ("pairs", 1)])
+def test_packed_anchor_mixed_case_reads_gpu(P, mode, anchors, ms):
+    """lower-case bases in anchored runs stay on the bit-plane kernels (marks for the case-sensitive anchor search, stored
+    codes for the upper-cased window): half of 60 k reads carry lower-case bases, some entirely; general_reads counts only
+    the reads that hold lower case AND a non-ACGT symbol; against the oracle"""
+    from test_lane_logic_cpu import lower_case_some
+    up, down = "GTTTAAGAGCTA", "CGTTACCAGGTT"
+    guides = P.binding.synth_library(4711, 150, 20)
+    kw = dict(mode=mode, miss=1, length=20, miss_search_up=ms, miss_search_down=ms)
+    feats = guides
+    if anchors == "pairs":
+        kw["upstream"] = up + "," + up; kw["downstream"] = down + "," + down
+        feats = [g + ":" + g for g in guides[:100]] + guides[100:]
+    else:
+        if anchors in ("both", "up"):
+            kw["upstream"] = up
+        if anchors in ("both", "down"):
+            kw["downstream"] = down
+    with P.Counter(features=feats if mode == "C" else None, **kw) as c:
+        fq = bytes(c.synth_fastq(guides=guides, seed=ms + 40, n_reads=60000, read_len=150, cassette=True, up=up, down=down, max_offset=100,
+                                 p_sub=0.2, p_lowq=0.1, p_n=0.01))
+        fq = lower_case_some(fq, 17)
+        orc = O.Oracle(features=[(str(i), s) for i, s in enumerate(feats)] if mode == "C" else None, **kw)
+        orc.count_fastq(fq)
+        _, t = c.count_block(fq, want_timing=True)
+        counts, stats = c.read_counts()
+        assert t["fast_reads"] + t["general_reads"] == 60000 and t["general_reads"] < (900 if anchors != "pairs" else 1500)
+        assert list(stats) == orc.stats()
+        if mode == "C":
+            assert list(counts) == orc.counts()
+        else:
+            assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(orc.keys(), orc.counts()))

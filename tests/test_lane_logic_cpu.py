@@ -446,6 +446,55 @@ def test_packed_anchor_with_odd_symbols(anchors):
             assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
 
 
+def lower_case_some(fastq, seed, share=0.5, rate=0.08, whole=0.1):
+    """rewrite bases of `share` of the reads in lower case (each base with probability `rate`; `whole` of those reads entirely)"""
+    import random
+    rng = random.Random(seed)
+    lines = fastq.split(b"\n")
+    for i in range(1, len(lines), 4):
+        if rng.random() < share:
+            b = bytearray(lines[i])
+            allb = rng.random() < whole
+            for j in range(len(b)):
+                if b[j] in b"ACGT" and (allb or rng.random() < rate):
+                    b[j] |= 0x20
+            lines[i] = bytes(b)
+    return b"\n".join(lines)
+
+
+@pytest.mark.parametrize("mode", ["C", "EC"])
+@pytest.mark.parametrize("anchors,ms", [("both", 1), ("up", 0), ("down", 2), ("pairs", 1)])
+def test_packed_anchor_mixed_case_reads(mode, anchors, ms):
+    """lower-case bases in anchored runs stay on the bit-plane path: they match no anchor symbol (the search is
+    case-sensitive, fast2q.py:337) yet are ordinary bases of the upper-cased window (:354) -- marked in the quality
+    plane for the anchors, their codes stored for the key (F2Q_LEN_CASE).  Half of the reads carry lower-case bases
+    (in anchors, windows, flanks; some reads entirely); a read with lower case AND an N takes the byte-exact routine."""
+    guides = synth.make_library(150, 20, 4711)
+    spec = synth.Spec(seed=ms + 40, n_reads=4000, read_len=150, cassette=True, up=UP, down=DOWN, max_offset=100, p_sub=0.2, p_lowq=0.1, p_n=0.01)
+    fq = lower_case_some(synth.make_fastq(spec, guides), 17)
+    kw = dict(mode=mode, miss=1, length=20, miss_search_up=ms, miss_search_down=ms)
+    feats = guides
+    if anchors == "pairs":
+        kw["upstream"] = UP + "," + UP; kw["downstream"] = DOWN + "," + DOWN
+        feats = [g + ":" + g for g in guides[:100]] + guides[100:]
+    else:
+        if anchors in ("both", "up"):
+            kw["upstream"] = UP
+        if anchors in ("both", "down"):
+            kw["downstream"] = DOWN
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(feats)] if mode == "C" else None, **kw)
+    o.count_fastq(fq)
+    e = Emu(features=feats if mode == "C" else None, **kw)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats()
+    assert e.anchor_reads() == fast and fast + gen == 4000 and gen < (60 if anchors != "pairs" else 120)     # lower case + N in one read, N with ':' features
+    if mode == "C":
+        assert counts == o.counts()
+    else:
+        assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
+
+
 @pytest.mark.parametrize("start,length,rl", [(0, 20, 150), (7, 29, 60), (3, 12, 14), (10, 8, 9), (0, 0, 30), (5, 30, 80)])
 def test_extract_count_fixed_window(start, length, rl):
     """Extract+Count with --st/--l on the packed path: clipped and empty windows, odd symbols, Phred filter"""
