@@ -186,7 +186,7 @@ def pmc_traffic(a, dominant):
                 return None, {"error": f"rocprofv3 --pmc {counter} failed (exit {r.returncode})", "stderr": r.stderr.decode(errors="replace")[-300:]}
             vals = []
             for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == counter and dominant in row["Kernel_Name"]:
+                if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in dominant.split("|")):
                     vals.append(float(row["Counter_Value"]))
             if not vals:
                 return None, {"error": f"no {dominant} dispatch in the {counter} pass"}
@@ -314,8 +314,9 @@ def end_to_end(pkg, c, fq, n_fq):
 
 
 def timed_steps(c, blk, steps, warmup, allreduce=None, barrier=None, sync=None):
+    path = 0
     for _ in range(warmup):
-        c.reset(); c.count_resident(blk)
+        c.reset(); path = c.count_resident(blk).get("path", 0)
         if allreduce:
             allreduce()
     if barrier:
@@ -336,7 +337,7 @@ def timed_steps(c, blk, steps, warmup, allreduce=None, barrier=None, sync=None):
     dt = time.perf_counter() - t0
     kern = c.queued_times()                        # kernel time of each of the K steps, read after the timed region
     assert len(kern) == steps, (len(kern), steps)
-    return dt, sum(kern) / len(kern)
+    return dt, sum(kern) / len(kern), path
 
 
 def main(argv=None, engine=None):
@@ -364,7 +365,9 @@ def main(argv=None, engine=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     name, scaling, w = resolve(a, world)
-    dominant = "k_extract_fixed4" if w.get("ec") and not w.get("anchored") else "k_count_anchor_pairs" if w.get("pairs") else "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4"
+    dominant = "k_extract_fixed4" if w.get("ec") and not w.get("anchored") else "k_count_anchor_pairs" if w.get("pairs") else "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4|k_part_"
+    # (a fixed window is counted by k_count_fixed4[_lds] or, large libraries, by the k_part_scatter / k_part_count / k_part_reduce
+    # sequence: the PMC passes sum whichever family the step launched; `roofline.kernel` names the one that ran, from f2q_timing.path)
 
     traffic, traffic_detail = None, {"error": "skipped"}
     if world == 1 and not a.no_pmc:
@@ -423,7 +426,9 @@ def main(argv=None, engine=None):
         if engine is None:
             torch.cuda.synchronize()
 
-    dt, k_ms = timed_steps(c, blk, a.steps, a.warmup, allreduce, barrier, sync)
+    dt, k_ms, path = timed_steps(c, blk, a.steps, a.warmup, allreduce, barrier, sync)
+    if "|" in dominant:
+        dominant = {4: "k_part_scatter + k_part_count + k_part_reduce", 3: "k_count_fixed4_lds", 2: "k_count_fixed4"}.get(path, "k_count_fixed4")
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -492,7 +497,7 @@ def main(argv=None, engine=None):
             try:
                 w4 = dict(WORKLOADS["cfg4_400M_100k_m1"])
                 c4, b4, _, _ = make_job(pkg, w4, a, device, w4["n_reads"], 0)
-                dt4, k4 = timed_steps(c4, b4, 3, 1, None, None, sync)
+                dt4, k4, _ = timed_steps(c4, b4, 3, 1, None, None, sync)
                 _, s4 = c4.read_counts()
                 out["strong_scaling_n1"] = {"workload": "cfg4_400M_100k_m1", "n_gpus": 1, "steps": 3, "value": w4["n_reads"] * 3 / dt4 / 1e6,
                                             "unit": "Mreads/s", "ms_per_step": dt4 / 3 * 1e3, "kernel_ms": k4,
