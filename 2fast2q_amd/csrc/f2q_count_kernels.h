@@ -711,7 +711,8 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev 
             const uint32_t want = (uint32_t)g.qw0 + (uint32_t)(r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
             const uint32_t row = want < pb.wq ? want : pb.wq - 1u;
             // a row past the tile's last one holds no byte of any read of the block: it must test as "nothing fails"
-            qrow[r] = (g.add_hi && want < pb.wq) ? ld_u4<true>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
+            // (the rows are fetched with the Phred rule off too: bit 7 of their bytes flags the window's 'N's)
+            qrow[r] = want < pb.wq ? ld_u4<true>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
         }
         uint32_t len01 = 0, len23 = 0;
         if (pb.len) {
@@ -732,12 +733,8 @@ __global__ __launch_bounds__(F2Q_V2_THREADS) void k_extract_fixed4(const RunDev 
             st[0]++;
             // bytes past the end of a short read are stored as 0 and never fail, so bad[] already is the clipped test
             if (bad[j]) { st[4]++; continue; }
-            const int rl = (int)(l & F2Q_LEN_MASK);
-            int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;             // Python slice clipping (:354)
-            if (L < 0) L = 0;
-            const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
             const uint64_t slot = (uint64_t)tile * F2Q_TILE + 4u * lane + (uint32_t)j;
-            n_new += ec64_insert_n(ec, key, L, read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
+            n_new += ec64_insert_word(ec, fixed4_ec_word(g, brow, qrow, j, l), read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
             st[1]++;
         }
     }
@@ -1523,8 +1520,9 @@ __global__ __launch_bounds__(256) void k_ec_deferred_slow(const RunDev *__restri
 // ---- Extract+Count with a fixed window and the hot keys in LDS ---------------------------------------------------------
 // k_extract_fixed4's tile walk (one wave per tile, 4 reads per lane) in front of k_extract_anchor_hot's counting stage:
 // amplicon-like samples repeat a few thousand windows, and those are counted in LDS instead of one device-scope atomic
-// per read.  A fixed window of <= 29 bases always has a single-word form and the packer passes no flagged read, so the
-// only reads set aside are those that meet a full table (k_ec_deferred_fixed inserts them after the table has grown).
+// per read.  The packer passes only reads whose window has a single-word form (<= 29 bases; with 'N's: what ec64_word
+// holds), so the only reads set aside are those that meet a full table (k_ec_deferred_fixed inserts them after the
+// table has grown).
 #define F2Q_FH_THREADS 1024
 #define F2Q_FH_WAVES (F2Q_FH_THREADS / 64)
 template <bool LEARN>
@@ -1565,7 +1563,7 @@ __global__ __launch_bounds__(F2Q_FH_THREADS) void k_extract_fixed4_hot(const Run
         for (int r = 0; r < F2Q_MAXQROWS; r++) {
             const uint32_t want = (uint32_t)g.qw0 + (uint32_t)(r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
             const uint32_t row = want < pb.wq ? want : pb.wq - 1u;
-            qrow[r] = (g.add_hi && want < pb.wq) ? ld_u4<true>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
+            qrow[r] = want < pb.wq ? ld_u4<true>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
         }
         uint32_t len01 = 0, len23 = 0;
         if (pb.len) {
@@ -1587,11 +1585,7 @@ __global__ __launch_bounds__(F2Q_FH_THREADS) void k_extract_fixed4_hot(const Run
             const bool live = l != F2Q_LEN_SKIP;
             ins[j] = live && !bad[j];
             st[0] += live; st[4] += live && bad[j];
-            const int rl = (int)(l & F2Q_LEN_MASK);
-            int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;             // Python slice clipping (:354)
-            if (L < 0) L = 0;
-            const uint64_t key = fixed4_key(g, brow, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
-            k[j] = ((unsigned long long)L << 58) | key;
+            k[j] = fixed4_ec_word(g, brow, qrow, j, l);                     // Python slice clipping (:354); 'N's spelt from the flag bits
             q[j] = hot_probe(k[j]);
             p1[j] = lds_k2(hk + 2u * q[j].b1); p2[j] = lds_k2(hk + 2u * q[j].b2);
         }
@@ -1656,8 +1650,9 @@ __global__ __launch_bounds__(256) void k_ec_deferred_fixed(const RunDev *__restr
         const uint64_t slot = gp(defer)[i] >> 32;
         if (slot >= pb.n_slots) continue;
         const uint32_t tile = (uint32_t)(slot / F2Q_TILE), in_tile = (uint32_t)(slot % F2Q_TILE), lane4 = in_tile >> 2, j = in_tile & 3u;
-        U4 brow[F2Q_MAXBROWS];
+        U4 brow[F2Q_MAXBROWS], qrow[F2Q_MAXQROWS];
         const auto bp = gp(pb.bases) + (uint64_t)tile * pb.wb * F2Q_TILE + 4u * lane4;
+        const auto qp = gp(pb.qual) + (uint64_t)tile * pb.wq * F2Q_TILE + 4u * lane4;
 #pragma unroll
         for (int r = 0; r < F2Q_MAXBROWS; r++) {
             uint32_t row = (uint32_t)g.bw0 + (uint32_t)(r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
@@ -1665,11 +1660,13 @@ __global__ __launch_bounds__(256) void k_ec_deferred_fixed(const RunDev *__restr
             brow[r] = ld_u4<false>(bp + (uint64_t)row * F2Q_TILE);
         }
         const uint32_t l = pb.len ? gp(pb.len)[slot] : pb.rmax;
-        const int rl = (int)(l & F2Q_LEN_MASK);
-        int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;
-        if (L < 0) L = 0;
-        const uint64_t key = fixed4_key(g, brow, (int)j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
-        n_new += ec64_insert_n(ec, key, L, read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
+#pragma unroll
+        for (int r = 0; r < F2Q_MAXQROWS; r++) {                   // the flag bits of a window with 'N's
+            const uint32_t want = (uint32_t)g.qw0 + (uint32_t)(r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
+            const uint32_t row = want < pb.wq ? want : pb.wq - 1u;
+            qrow[r] = ((l & F2Q_LEN_FLAG) && want < pb.wq) ? ld_u4<false>(qp + (uint64_t)row * F2Q_TILE) : U4{0, 0, 0, 0};
+        }
+        n_new += ec64_insert_word(ec, fixed4_ec_word(g, brow, qrow, (int)j, l), read_base + pb.first_index + (pb.index ? (uint64_t)gp(pb.index)[slot] : slot));
         st[1]++;
     }
     ec64_report_new(ec, n_new);

@@ -1167,6 +1167,21 @@ F2Q_HD uint32_t fixed4_flags(const FixedGeom &g, const U4 (&q)[QR], int j)
     return (uint32_t)(bits >> (g.st & 3));
 }
 
+// Extract+Count with a fixed window: the single-word key of read j of a lane (l = its length word).  The window is
+// clipped to the read like a Python slice (fast2q.py:354); an 'N' inside it travels as a flag bit and is spelt into the
+// word (ec64_word) -- the packer passes only reads whose window has a single-word form (read_is_clean).
+template <int BR, int QR>
+F2Q_HD unsigned long long fixed4_ec_word(const FixedGeom &g, const U4 (&b)[BR], const U4 (&q)[QR], int j, uint32_t l)
+{
+    const int rl = (int)(l & F2Q_LEN_MASK);
+    int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;
+    if (L < 0) L = 0;
+    const uint64_t key = fixed4_key(g, b, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
+    unsigned long long w = ((unsigned long long)L << 58) | key;
+    if (l & F2Q_LEN_FLAG) ec64_word(key, fixed4_flags(g, q, j) & (uint32_t)((1ull << L) - 1ull), L, w);
+    return w;
+}
+
 // pigeonhole search on the packed piece tables; forced2 = 2-bit-spaced mask of query positions that
 // mismatch every feature (non-ACGT symbols).  The first slot of every piece's chain (up to 4 pieces) is
 // fetched before any chain is walked, so the usual m = 1 lookup costs one memory round trip, not two.
@@ -1847,7 +1862,7 @@ struct PackPlan {
     int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
     int from = 0;                  // ... and only [from, need) is ever looked at
     bool inband_n = false;         // non-ACGT symbols travel as flag bits (all-ACGT library only)
-    bool n_only = false;           // ... but only the symbol 'N' (Extract+Count: the key spells the symbol, a flag reads 'N')
+    bool n_only = false;           // ... but only the symbol 'N' (Extract+Count: the key spells the symbol, a flag reads 'N'; fixed windows: 'n' too, upper-cased)
     bool fast_anchor = false;      // --us/--ds with ACGT anchors: packed bit-plane path
     bool multi_pair = false;       // ... several pairs: k_count_anchor_pairs (one search per pair on the same planes)
     int kb = 1;                    // counter bits of the anchor search (0: exact, 1: k <= 1, 3: k <= 7)
@@ -1879,10 +1894,17 @@ F2Q_HD bool read_is_clean(const PackPlan &pl, const RecT<P> &r)
     if (!pl.fast_fixed) return false;
     if (r.qlen != r.len) return false;
     const uint32_t b = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
+    uint32_t nmask = 0;
     for (uint32_t j = (uint32_t)pl.from; j < b; j++) {
-        if (base_code(up8(r.seq[j])) > 3u && !pl.inband_n) return false;     // the window is upper-cased (:354)
+        const uint8_t c = up8(r.seq[j]);                                      // the window is upper-cased (:354)
+        if (base_code(c) > 3u) {
+            if (!pl.inband_n || (pl.n_only && c != 'N')) return false;
+            nmask |= 1u << ((j - (uint32_t)pl.from) & 31u);
+        }
         if (r.qual[j] & 0x80) return false;
     }
+    // Extract+Count: the key spells its 'N's, and the packed kernels make single-word keys only
+    if (pl.n_only && nmask && !ec64_fits(nmask, (int)(b - (uint32_t)pl.from))) return false;
     return true;
 }
 

@@ -466,6 +466,8 @@ inline PackPlan make_plan(const RunDev &run)
     // anchored Extract+Count: a read with 'N's keeps to the packed path (an 'N' equals no anchor base; a window that
     // holds one is spelt out from the planes and the flag bits), any other odd symbol sends the read to the byte-exact path
     if (run.mode == 1 && pl.fast_anchor) { pl.inband_n = true; pl.n_only = true; }
+    // Extract+Count with a fixed window: the same for windows whose 'N's fit the single-word key (read_is_clean asks ec64_fits)
+    if (run.mode == 1 && pl.fast_fixed && !pl.multi) { pl.inband_n = true; pl.n_only = true; }
     return pl;
 }
 

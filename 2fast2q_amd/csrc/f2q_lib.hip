@@ -1160,12 +1160,15 @@ static int launch_block(f2q_ctx *c, const f2q_block *b, f2q_timing *t, hipEvent_
     HIPC(c, hipEventRecord(k1, c->stream));
     c->reads_seen += b->n_reads;
 #ifdef F2Q_STAMP
-    { unsigned long long h[4]; (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(h, acc.stamp, 32, hipMemcpyDeviceToHost);
+    { unsigned long long h[8]; (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(h, acc.stamp, 64, hipMemcpyDeviceToHost);
       (void)hipMemset(acc.stamp, 0, 64);
-      unsigned long long tot = h[0] + h[1] + h[2] + h[3];
-      if (tot) fprintf(stderr, "[stamp] phase 0 %.1f%%  1 %.1f%%  2 %.1f%%  3 %.1f%%  (%.0f clock ticks/wave-tile)\n",
-                       100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot,
-                       (double)tot / ((double)b->pb.n_tiles * 4)); }
+      unsigned long long tot = 0;
+      for (int i = 0; i < 8; i++) tot += h[i];
+      if (tot) {
+          fprintf(stderr, "[stamp]");
+          for (int i = 0; i < 8; i++) if (h[i]) fprintf(stderr, " phase %d %.1f%%", i, 100.0 * h[i] / tot);
+          fprintf(stderr, "  (%.0f clock ticks/wave-tile)\n", (double)tot / ((double)b->pb.n_tiles * 4));
+      } }
 #endif
     if (t) {
         HIPC(c, hipEventSynchronize(k1));

@@ -271,6 +271,12 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
     // Table 1 is asked for ONE bucket, the first-choice one: its first tag says whether any feature of that bucket had to
     // move to its second choice (PtDesc::spill; table 1 is kept at load 0.2, so fewer than 1 % of the buckets say so),
     // and only then is the second bucket read -- by the few lanes concerned, in the deciding half.
+#ifdef F2Q_STAMP
+    unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime(), t1_;
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
     struct NearBatch { LtProbe q; U2 e[4]; uint32_t forced; uint32_t n; };
     auto near_ask = [&](NearBatch &nb, uint32_t n) {
         nb.n = n;
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
         if (pt.spill) {
             const bool more = lane < nb.n && nb.e[2].x != F2Q_LT_EMPTY && (nb.e[2].x & pt.spill) != 0u;
             if (nb.e[2].x != F2Q_LT_EMPTY) nb.e[2].x &= ~pt.spill;  // (an empty first slot with the mark stays what it is: it equals no tag)
+            PSTAMP(4);
             if (__ballot(more)) {
                 if (more) { const v2 t3 = *(const v2 F2Q_GLOBAL *)(tags1 + 2u * nb.q.b[3]); nb.e[3] = U2{t3.x, t3.y}; }
                 if (nb.e[3].x != F2Q_LT_EMPTY) nb.e[3].x &= ~pt.spill;   // (that bucket is some other half's first choice: its mark is not ours)
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
         } else if (lane < nb.n) {
             const v2 t3 = *(const v2 F2Q_GLOBAL *)(tags1 + 2u * nb.q.b[3]); nb.e[3] = U2{t3.x, t3.y};
         }
+        PSTAMP(5);
         uint32_t hit = 0, hitw = 0;
         const uint32_t ncand = lt_near1(lt, nb.q, nb.e, nb.forced, hit, hitw);
         const bool imp = lane < nb.n && ncand == 1u, far = imp && (hit >> 31) != 0u;
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
         // a hit through table 1 is another partition's feature: its table-1 slot is noted in LDS and hist1 receives 64 of
         // them with one instruction (a global atomic in every batch would sit in the wave's queue of memory operations
         // behind the entries requested for the coming steps -- and make the next wait for entries wait for those too)
+        PSTAMP(6);
         const unsigned long long fm = __ballot(far);
         if (far) via[(v_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))) & (F2Q_PC_VIA - 1u)] = hit & 0x7FFFFFFFu;
         v_tail += (uint32_t)__popcll(fm);
@@ -318,6 +327,7 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
             v_head += 64u;
         }
         w_imperfect += (uint32_t)__popcll(__ballot(imp));
+        PSTAMP(7);
     };
     auto step = [&](const v4 &ev, const Pos &c) {
         const unsigned long long ent[2] = {((unsigned long long)ev.y << 32) | ev.x, ((unsigned long long)ev.w << 32) | ev.z};
@@ -362,12 +372,6 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
             }
         }
     };
-#ifdef F2Q_STAMP
-    unsigned long long tp[4] = {0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime(), t1_;
-#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); tp[i] += t1_ - t0_; t0_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PSTAMP(i) do {} while (0)
-#endif
     // one round: ask for a batch of the ring (or for nothing), request the entries three rounds ahead, take this round's
     // exact hits, decide the batch asked for in the last round; a ring that still holds 128 entries or more (a stretch of
     // reads without exact hits) is brought below that before the next round pushes up to 128 more
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
         PSTAMP(1);
         if (NEAR && due.n) near_decide(due);
         if (NEAR) while (r_tail - r_head >= 128u) { NearBatch nb2; near_ask(nb2, 64u); near_decide(nb2); }
-        PSTAMP(2);
+        PSTAMP(7);
     };
 
     // four register sets of entries in rotation: the set requested in one round is consumed three rounds later
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(F2Q_PC_THREADS) void k_part_count(const RunDev *__r
         }
     }
 #ifdef F2Q_STAMP
-    if (lane == 0 && acc.stamp) for (int i = 0; i < 4; i++) atomicAdd(&acc.stamp[i], tp[i]);
+    if (lane == 0 && acc.stamp) for (int i = 0; i < 8; i++) atomicAdd(&acc.stamp[i], tp[i]);
 #endif
     if (NEAR) while (r_tail != r_head) { NearBatch nb; const uint32_t left = r_tail - r_head; near_ask(nb, left < 64u ? left : 64u); near_decide(nb); }
     if (NEAR && lane < v_tail - v_head)

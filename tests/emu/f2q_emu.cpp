@@ -242,7 +242,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     const uint32_t want = g.qw0 + (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
                     const uint32_t row = want < pb.wq ? want : pb.wq - 1;
                     const uint32_t *p = qp + (uint64_t)row * F2Q_TILE;
-                    qr[r] = (g.add_hi && want < pb.wq) ? U4{p[0], p[1], p[2], p[3]} : U4{0, 0, 0, 0};
+                    qr[r] = want < pb.wq ? U4{p[0], p[1], p[2], p[3]} : U4{0, 0, 0, 0};
                 }
                 if (g.add_hi)
                     for (int r = 0; r < F2Q_MAXQROWS; r++)
@@ -252,11 +252,7 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     if (l == F2Q_LEN_SKIP) continue;
                     acc.stats[0]++; e->v2_reads++;
                     if (bad[j]) { acc.stats[4]++; continue; }
-                    const int rl = (int)(l & F2Q_LEN_MASK);
-                    int L = (rl < g.st + g.L ? rl : g.st + g.L) - g.st;
-                    if (L < 0) L = 0;
-                    const uint64_t key = fixed4_key(g, b, j) & (L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull));
-                    ec64_insert(e->ec, key, L, e->reads_seen + hp_index[(uint64_t)t * F2Q_TILE + 4 * lane + j]);
+                    if (ec64_insert_word(e->ec, fixed4_ec_word(g, b, qr, j, l), e->reads_seen + hp_index[(uint64_t)t * F2Q_TILE + 4 * lane + j])) e->ec.ctr[3]++;
                     acc.stats[1]++;
                 }
             }

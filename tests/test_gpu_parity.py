@@ -801,6 +801,43 @@ def test_extract_count_fixed_window_gpu(P, start, length, rl):
         assert (t["fast_reads"] > 0) == (length <= 29)
 
 
+@pytest.mark.parametrize("hot", ["1", "0"], ids=["hot_keys", "stepped"])
+@pytest.mark.parametrize("host_pack", ["0", "1"], ids=["device_packer", "host_packer"])
+@pytest.mark.parametrize("start,length,rl,rate", [(0, 20, 150, 0.03), (5, 26, 40, 0.04), (2, 29, 31, 0.02), (4, 12, 14, 0.1)])
+def test_extract_count_fixed_window_n_reads_stay_packed_gpu(P, monkeypatch, start, length, rl, rate, host_pack, hot):
+    """Extract+Count with --st/--l: windows with up to three 'N' / 'n' keep to the tiles (single-word keys spelt from the
+    flag bits) in k_extract_fixed4_hot, the stepped k_extract_fixed4 and, with a table that fills up, k_ec_deferred_fixed"""
+    def fits(nn, n):
+        return n <= 29 and nn <= 3 and 2 * n + 2 + 5 * nn <= 58
+    monkeypatch.setenv("F2Q_HOST_PACK", host_pack)
+    if hot == "0":
+        monkeypatch.setenv("F2Q_NO_HOT", "1")
+    else:
+        monkeypatch.setenv("F2Q_HOT_LEARN", "2000")
+    guides = synth.make_library(60, max(8, min(length, 20)), 778)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=start + length, n_reads=30000, read_len=rl, start=start, p_lowq=0.1), guides),
+                          5, rate=rate, symbols=b"Nn")
+    kw = dict(mode="EC", start=str(start), length=length)
+    o = O.Oracle(**kw)
+    o.count_fastq(fq)
+    want_gen = 0
+    for seq in fq.split(b"\n")[1::4]:
+        w = seq[start:start + length].upper()
+        want_gen += bool(w.count(b"N")) and not fits(w.count(b"N"), len(w))
+    with P.Counter(**kw) as c:
+        lines = fq.split(b"\n")
+        cut = 4 * (len(lines) // 8)                                      # two blocks: the table grows between them
+        for part in (b"\n".join(lines[:cut]) + b"\n", b"\n".join(lines[cut:])):
+            c.count_block(part)
+        _, stats = c.read_counts()
+        assert list(stats) == o.stats()
+        assert [(k, n) for k, n, _ in c.ec_results()] == list(zip(o.keys(), o.counts()))
+    with P.Counter(**kw) as c:
+        _, t = c.count_block(fq, want_timing=True)
+        assert t["general_reads"] == want_gen and t["fast_reads"] == 30000 - want_gen
+    assert any("N" in k for k in o.keys())
+
+
 def test_fuzz_kernels_vs_oracle(P):
     """2000 seeded random cases (tests/fuzz_cases.py) through the C ABI: device packer + every kernel family"""
     from fuzz_cases import make_case

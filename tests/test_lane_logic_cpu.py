@@ -513,6 +513,32 @@ def test_extract_count_fixed_window(start, length, rl):
     assert (fast > 0) == (length <= 29)          # windows longer than 29 bases use the byte-string table (general path)
 
 
+@pytest.mark.parametrize("start,length,rl,rate", [(0, 20, 150, 0.03), (5, 26, 40, 0.04), (2, 29, 31, 0.02), (4, 12, 14, 0.1)])
+def test_extract_count_fixed_window_n_reads_stay_packed(start, length, rl, rate):
+    """Extract+Count with --st/--l: a window with up to three 'N' / 'n' has a single-word key and stays on the tiles
+    (round 3; such reads took the byte-exact kernel before); more 'N's, or a window too long to spell them, do not"""
+    def fits(nn, n):                                  # ec64_word's rule (f2q_device.h)
+        return n <= 29 and nn <= 3 and 2 * n + 2 + 5 * nn <= 58
+    guides = synth.make_library(60, max(8, min(length, 20)), 778)
+    fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=start + length, n_reads=3000, read_len=rl, start=start, p_lowq=0.1), guides),
+                          5, rate=rate, symbols=b"Nn")
+    kw = dict(mode="EC", start=str(start), length=length)
+    o = O.Oracle(**kw)
+    o.count_fastq(fq)
+    e = Emu(**kw)
+    e.count_block(fq)
+    _, stats, fast, gen = e.read()
+    assert stats == o.stats()
+    assert [(k, n) for k, n, _ in e.ec_rows()] == list(zip(o.keys(), o.counts()))
+    want_gen = 0
+    for seq in fq.split(b"\n")[1::4]:
+        w = seq[start:start + length].upper()
+        nn = w.count(b"N")
+        want_gen += bool(nn) and not fits(nn, len(w))
+    assert gen == want_gen and fast + gen == 3000
+    assert any("N" in k for k in o.keys())
+
+
 def test_fuzz_lane_logic_vs_oracle():
     """400 seeded random cases (tests/fuzz_cases.py): every mode, awkward symbols / lengths / framing"""
     from fuzz_cases import make_case
