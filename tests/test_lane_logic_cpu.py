@@ -109,11 +109,12 @@ def test_lds_tables_vs_oracle(miss, glen, n_guides, start):
 
 @pytest.mark.parametrize("miss", [0, 1])
 @pytest.mark.parametrize("glen,n_guides,start,parts", [(20, 9000, 0, 3), (20, 30000, 3, 0), (21, 6000, 2, 5), (17, 2000, 9, 2), (18, 20000, 0, 0),
-                                                        (14, 800, 5, 4)])
+                                                        (14, 800, 5, 4), (20, 10000, 0, 1), (19, 3000, 7, 1)])
 def test_partitioned_tables_vs_oracle(miss, glen, n_guides, start, parts):
     """k_part_scatter / k_part_count's per-read logic (a library dealt into partitions by half 0: table 0 per partition,
     one table 1 over all features; a hit through table 1 counted by its table-1 slot) against the oracle -- on libraries
-    beyond one workgroup's LDS (parts = 0: the builder chooses) and on small ones forced into partitions, with the
+    beyond one workgroup's LDS (parts = 0: the builder chooses), on small ones forced into partitions and on ONE partition
+    (the tables k_part_fused works on), with the
     same near-duplicate features, heavy mutation, N symbols and clipped windows as the LDS-table test."""
     guides = synth.make_library(n_guides, glen, 77 * glen + n_guides)
     twins = []
