@@ -191,7 +191,7 @@ struct EcDev {
     // keys that are plain ACGT strings of <= 29 bases live in a second, single-word table:
     // slot = (length << 58) | 2-bit key, claimed with one CAS; ~0 = empty
     unsigned long long *k64_slots;
-    unsigned long long *k64_count;
+    unsigned long long *k64_count;     // reads that carried the slot's key, MINUS ONE (a new key costs one atomic less: two out of three reads that reach this table bring a new key)
     unsigned long long *k64_first;
     uint32_t k64_mask, k64_room;       // slots - 1; keys the table may hold before it grows (3/4 of the slots)
 };
@@ -831,7 +831,7 @@ F2Q_HD uint32_t ec64_insert_word(const EcDev &ec, unsigned long long k, unsigned
             if (v == KEY_EMPTY) { fresh = 1; v = k; }
         }
         if (v == k) {
-            ec_fetch_add(&ec.k64_count[s], 1ull);
+            if (!fresh) ec_fetch_add(&ec.k64_count[s], 1ull);    // the count word holds n - 1: the read that claims a slot need not touch it
             // the minimum only ever decreases: a plain look first saves the read-modify-write for almost every read
             if (read_index < F2Q_LD64(&ec.k64_first[s])) ec_min(&ec.k64_first[s], read_index);
             return fresh;
@@ -864,7 +864,9 @@ F2Q_HD uint32_t ec64_try_insert(const EcDev &ec, unsigned long long k, unsigned 
             if (v == KEY_EMPTY) { fresh = 1; v = k; }
         }
         if (v == k) {
-            if (WANT_COUNT) count_before = ec_fetch_add(&ec.k64_count[s], 1ull);
+            // (the count word holds n - 1, see ec64_insert_word; count_before = reads that carried the key before this one)
+            if (fresh) count_before = 0;
+            else if (WANT_COUNT) count_before = ec_fetch_add(&ec.k64_count[s], 1ull) + 1ull;
             else ec_add(&ec.k64_count[s], 1ull);
             slot = s;
             if (read_index < f) ec_min(&ec.k64_first[s], read_index);

@@ -2266,7 +2266,7 @@ static int ec_pull(f2q_ctx *c, EcHost &h)
             if (ks[i] == KEY_EMPTY) continue;
             char text[32];
             const uint32_t len = ec64_text(ks[i], text);
-            h.keys.emplace_back(text, len); h.cnt.push_back(kc[i]); h.first.push_back(kf[i]);
+            h.keys.emplace_back(text, len); h.cnt.push_back(kc[i] + 1ull); h.first.push_back(kf[i]);      // (the word holds n - 1)
         }
     }
     return F2Q_OK;

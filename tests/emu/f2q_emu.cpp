@@ -483,7 +483,7 @@ void emu_ec_get(void *h, uint64_t e_, char *key, uint32_t *len, int64_t *count, 
     if (e_ >= e->ctr[0]) {
         const size_t s = k64_live(e)[e_ - e->ctr[0]];
         const unsigned long long k = e->k64s[s];
-        *len = ec64_text(k, key); *count = (int64_t)e->k64c[s]; *first = e->k64f[s];
+        *len = ec64_text(k, key); *count = (int64_t)e->k64c[s] + 1; *first = e->k64f[s];
         return;
     }
     *len = e->ent_len[e_]; *count = (int64_t)e->ent_count[e_]; *first = e->ent_first[e_];
