@@ -299,14 +299,16 @@ def end_to_end(pkg, c, fq, n_fq):
             out[key] = n_fq / dt / 1e6
         import gzip
         pz = os.path.join(d, "x.fastq.gz")
-        cut = fq[: len(fq) // 4]
+        cut = fq[: len(fq) // 2]                                       # (half of the sample: compressing it here takes ~6 s)
         cut = cut[: cut.rfind(b"\n@r") + 1]
         nz = cut.count(b"\n") // 4
-        with gzip.open(pz, "wb", compresslevel=1) as f:
+        with gzip.open(pz, "wb", compresslevel=1) as f:               # ONE deflate stream, as `gzip -1` writes it
             f.write(cut)
-        c.reset(); t0 = time.perf_counter(); c.count_file(pz); _, st = c.read_counts(); dt = time.perf_counter() - t0
-        out["gzip_file_to_counts"] = nz / dt / 1e6
+        for key in ("gzip_file_first", "gzip_file_to_counts"):         # second pass: the decoder's buffers exist
+            c.reset(); t0 = time.perf_counter(); c.count_file(pz); _, st = c.read_counts(); dt = time.perf_counter() - t0
+            out[key] = nz / dt / 1e6
         out["gzip_sample_reads"] = int(st[0])
+        out["gzip_note"] = "ordinary single-member .gz; the worker pool (F2Q_IO_THREADS, default min(cores, 16)) decodes chunks of the one deflate stream"
     finally:
         shutil.rmtree(d, ignore_errors=True)
     c.reset()
