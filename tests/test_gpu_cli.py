@@ -103,7 +103,7 @@ def test_empty_and_tiny_files(tmp_path):
             c.count_file(str(tmp_path / "does_not_exist.fastq"))
 
 
-@pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf"])
+@pytest.mark.parametrize("kind", ["plain", "gzip", "gzip_par", "bgzf"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_count_file_shard_sums_to_the_whole(tmp_path, monkeypatch, kind, world):
     """f2q_count_file_shard: `world` contexts (one per rank) on the same file; pieces dealt round robin, framing global.
@@ -114,8 +114,10 @@ def test_count_file_shard_sums_to_the_whole(tmp_path, monkeypatch, kind, world):
     guides = synth.make_library(150, 20, 5)
     fq = sprinkle_symbols(synth.make_fastq(synth.Spec(seed=31, n_reads=12000, read_len=101), guides), 3, rate=0.004)
     fq = fq.replace(b"\n", b"\r\n", 500) + b"@tail\nACGT"              # CRLF lines and a partial record at the end
+    if kind == "gzip_par":                                            # the one deflate stream decoded by the worker pool, in 64 KiB chunks
+        monkeypatch.setenv("F2Q_GZ_PAR_MIN_KB", "16"); monkeypatch.setenv("F2Q_GZ_CHUNK_KB", "64")
     path = tmp_path / ("s.fastq" if kind == "plain" else "s.fastq.gz")
-    path.write_bytes({"plain": fq, "gzip": gzip.compress(fq, 1), "bgzf": bgzf_bytes(fq, block=30000)}[kind])
+    path.write_bytes({"plain": fq, "gzip": gzip.compress(fq, 1), "gzip_par": gzip.compress(fq, 6), "bgzf": bgzf_bytes(fq, block=30000)}[kind])
     for kw in (dict(miss=1), dict(mode="EC", start="5", length=18), dict(mode="EC", upstream="ACGT", length=9)):
         feats = guides if "mode" not in kw else None
         orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)] if feats else None, **kw)
@@ -382,7 +384,7 @@ def test_console_script_like_the_reference_test(tmp_path):
     assert len(files) == 6 and (subdirs[0] / "compiled.csv").exists()
 
 
-@pytest.mark.parametrize("gz", ["plain", "gzip", "bgzf"])
+@pytest.mark.parametrize("gz", ["plain", "gzip", "gzip_par", "bgzf"])
 @pytest.mark.parametrize("chunk", ["4096", "65536", "1000003"])
 @pytest.mark.parametrize("staging", ["as_it_comes", "every_piece", "never"])
 def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk, staging):
@@ -400,8 +402,10 @@ def test_file_streaming_across_chunk_boundaries(tmp_path, monkeypatch, gz, chunk
     fq += synth.make_fastq(synth.Spec(seed=82, n_reads=300, read_len=75), guides)
     fq += b"@huge\n" + guides[7].encode() + b"ACGT" * 20000 + b"\n+\n" + b"I" * 80020 + b"\n"   # 80 kb: longer than the carry head room
     fq += synth.make_fastq(synth.Spec(seed=81, n_reads=500, read_len=40), guides)[:-1]   # no final newline
+    if gz == "gzip_par":                                              # the worker pool on the one deflate stream (f2q_pargz.h)
+        monkeypatch.setenv("F2Q_GZ_PAR_MIN_KB", "16"); monkeypatch.setenv("F2Q_GZ_CHUNK_KB", "64")
     path = tmp_path / ("f.fastq" if gz == "plain" else "f.fastq.gz")
-    path.write_bytes({"plain": fq, "gzip": gzip.compress(fq, 1), "bgzf": bgzf_bytes(fq, block=20000)}[gz])
+    path.write_bytes({"plain": fq, "gzip": gzip.compress(fq, 1), "gzip_par": gzip.compress(fq, 1), "bgzf": bgzf_bytes(fq, block=20000)}[gz])
     for kw in (dict(miss=1), dict(mode="EC", upstream="ACGT", length=9)):
         orc = O.Oracle(features=[(str(i), g) for i, g in enumerate(guides)] if "mode" not in kw else None, **kw)
         orc.count_fastq(fq)
