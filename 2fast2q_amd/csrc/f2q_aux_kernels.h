@@ -53,6 +53,7 @@ struct SynthOut {
     unsigned long long *g_count; unsigned long long g_cap;
     int all_general;           // 1: every read is written as a raw record
     int inband_n;              // 1: an 'N' inside the window is flagged in place instead of taking the general path
+    int n_win, win_len, win_end, win_start[F2Q_MW_MAX];   // multi-window runs: only the windows are stored (PackPlan::n_win)
 };
 
 __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *__restrict__ guide_keys, SynthOut o,
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
     bool dirty = o.all_general != 0;
     const int npos = (r.n_pos >= 0 && r.wstart + r.n_pos < R) ? r.wstart + r.n_pos : -1;
     if (!dirty && npos >= 0 && !o.inband_n) dirty = true;
+    if (!dirty && o.n_win && R < o.win_end) dirty = true;        // a window the read ends in
     if (dirty) {
         if (o.len) o.len[slot] = (uint16_t)F2Q_LEN_SKIP;
         unsigned long long g = atomicAdd(o.g_count, 1ull);
@@ -85,9 +87,26 @@ __global__ __launch_bounds__(F2Q_TILE) void k_synth(SynthDev s, const uint64_t *
         // the packed slot stays zero-filled and is skipped through the len plane
         return;
     }
-    if (o.len) o.len[slot] = (uint16_t)((uint32_t)R | (npos >= 0 ? F2Q_LEN_FLAG : 0u));
     uint32_t *bp = o.bases + (tile * o.wb) * F2Q_TILE + lane;
     uint32_t *qp = o.qual + (tile * o.wq) * F2Q_TILE + lane;
+    if (o.n_win) {                               // several windows: their bases and quality bytes back to back, nothing else
+        const int S = o.n_win * o.win_len;
+        uint64_t fw = 0; int fwi = -1; bool fl = false;
+        uint32_t bw = 0, qw = 0;
+        for (int k = 0; k < S; k++) {
+            const int p = o.win_start[k / o.win_len] + k % o.win_len;
+            if ((p >> 5) != fwi) { fwi = p >> 5; fw = rnd(s.seed, i, F_FLANK0 + fwi); }
+            uint32_t code = base_code(synth_base(s, r, p, fw)); if (code > 3u) code = 0;
+            fl |= p == npos;
+            qw |= ((uint32_t)((p == r.qpos) ? r.qchar : (uint8_t)'I') | (p == npos ? 0x80u : 0u)) << (8 * (k & 3));
+            if ((k & 3) == 3 || k == S - 1) { qp[(uint64_t)(k >> 2) * F2Q_TILE] = qw; qw = 0; }
+            bw |= code << (2 * (k & 15));
+            if ((k & 15) == 15 || k == S - 1) { bp[(uint64_t)(k >> 4) * F2Q_TILE] = bw; bw = 0; }
+        }
+        if (o.len) o.len[slot] = (uint16_t)((uint32_t)S | (fl ? F2Q_LEN_FLAG : 0u));
+        return;
+    }
+    if (o.len) o.len[slot] = (uint16_t)((uint32_t)R | (npos >= 0 ? F2Q_LEN_FLAG : 0u));
     uint64_t fw = 0;
     uint32_t bw = 0, qw = 0, lw = 0, hw = 0;
     for (int p = 0; p < R; p++) {

@@ -61,7 +61,7 @@ struct RunDev {
     uint8_t down[F2Q_DEV_MAX_ITER][F2Q_ANCHOR_MAX];
     // packed anchored path (one --us/--ds pair, ACGT-only anchors of 1..32 bases): 2-bit codes of pair 0
     int32_t anchors_packed;            // 1: up_codes/down_codes are valid
-    int32_t pad_;
+    int32_t compact;                   // 1: several --st windows whose bases the tiles hold back to back, window w at stored position w * length (PackPlan::n_win)
     uint64_t up_codes, down_codes;     // symbol j = (codes >> 2j) & 3  -- one scalar load, no per-symbol memory access
     uint32_t up_pos[4], down_pos[4];   // per symbol c: bit j set iff anchor symbol j == c
     // several --us/--ds pairs, every anchor ACGT-only and 1..32 long: the same masks per pair (k_count_anchor_pairs)
@@ -1254,7 +1254,7 @@ F2Q_HD int packed_near_decide(const RunDev &run, const LibDev &lib, uint64_t key
 // the part count k, fast2q.py:349-363) and looked up among the k-part features.  One lane = 4 reads, windows one after
 // another.  geometry of window w = that of a single-window run starting at run.start[w].
 // ---------------------------------------------------------------------------------------------
-F2Q_HD FixedGeom fixed_geom_of(const RunDev &run, int w) { return fixed_geom_at(run.start[w], run.length, run.thr); }
+F2Q_HD FixedGeom fixed_geom_of(const RunDev &run, int w) { return fixed_geom_at(run.compact ? w * run.length : run.start[w], run.length, run.thr); }
 
 // ---------------------------------------------------------------------------------------------
 // LDS tables: the whole library inside the workgroup's LDS (north star: "the feature table tiled into LDS").
@@ -1863,6 +1863,11 @@ struct PackPlan {
     bool multi = false;            // fixed offset, 2..4 windows of n bases each, k * n <= 31, Counter mode
     int need = 0;                  // fixed mode: bases [0, need) are all the fast kernel can touch
     int from = 0;                  // ... and only [from, need) is ever looked at
+    // `multi`: the tiles hold ONLY the windows' bases and quality bytes, window w at stored positions [w * win_len,
+    // (w + 1) * win_len) -- windows far apart in the read (dual-guide vectors) cost the kernels no more rows than one
+    // window of n_win * win_len bases; need = n_win * win_len, from = 0.  A read that ends inside a window is not packed.
+    int n_win = 0, win_len = 0, win_end = 0;       // win_end: every window lies inside [0, win_end) of the read
+    int win_start[F2Q_MW_MAX] = {0, 0, 0, 0};
     bool inband_n = false;         // non-ACGT symbols travel as flag bits (all-ACGT library only)
     bool n_only = false;           // ... but only the symbol 'N' (Extract+Count: the key spells the symbol, a flag reads 'N'; fixed windows: 'n' too, upper-cased)
     bool fast_anchor = false;      // --us/--ds with ACGT anchors: packed bit-plane path
@@ -1872,6 +1877,8 @@ struct PackPlan {
 
 template <class P>
 struct RecT { P seq; P qual; uint32_t len, qlen; };
+// read position of stored position s (fixed-offset tiles)
+F2Q_HD uint32_t pack_src(const PackPlan &pl, uint32_t s) { return pl.n_win ? (uint32_t)pl.win_start[s / (uint32_t)pl.win_len] + s % (uint32_t)pl.win_len : s; }
 
 // Can this read go through a packed fast path?  The planes cannot carry a quality line of another length or
 // quality bytes >= 128 (bit 7 is the flag bit and the Phred SWAR test relies on 7-bit bytes); non-ACGT symbols
@@ -1895,15 +1902,17 @@ F2Q_HD bool read_is_clean(const PackPlan &pl, const RecT<P> &r)
     }
     if (!pl.fast_fixed) return false;
     if (r.qlen != r.len) return false;
-    const uint32_t b = r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need;
+    if (pl.n_win && r.len < (uint32_t)pl.win_end) return false;              // a window the read ends in: the byte-exact routine clips it
+    const uint32_t b = pl.n_win ? (uint32_t)pl.need : (r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need);
     uint32_t nmask = 0;
     for (uint32_t j = (uint32_t)pl.from; j < b; j++) {
-        const uint8_t c = up8(r.seq[j]);                                      // the window is upper-cased (:354)
+        const uint32_t at = pack_src(pl, j);
+        const uint8_t c = up8(r.seq[at]);                                     // the window is upper-cased (:354)
         if (base_code(c) > 3u) {
             if (!pl.inband_n || (pl.n_only && c != 'N')) return false;
             nmask |= 1u << ((j - (uint32_t)pl.from) & 31u);
         }
-        if (r.qual[j] & 0x80) return false;
+        if (r.qual[at] & 0x80) return false;
     }
     // Extract+Count: the key spells its 'N's, and the packed kernels make single-word keys only
     if (pl.n_only && nmask && !ec64_fits(nmask, (int)(b - (uint32_t)pl.from))) return false;
@@ -1914,7 +1923,7 @@ F2Q_HD bool read_is_clean(const PackPlan &pl, const RecT<P> &r)
 template <class P>
 F2Q_HD uint32_t packed_len(const PackPlan &pl, const RecT<P> &r)
 {
-    return pl.fast_anchor ? r.len : (r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need);
+    return pl.fast_anchor ? r.len : pl.n_win ? (uint32_t)pl.need : (r.len < (uint32_t)pl.need ? r.len : (uint32_t)pl.need);
 }
 
 // tile geometry for a block whose longest stored read is rmax_in
@@ -1950,7 +1959,7 @@ F2Q_HD void pack_read(const PackPlan &pl, const RecT<P> &r, uint32_t planar_nw, 
         for (uint32_t w = 0; w * 16 < l; w++) {
             uint32_t v = 0;
             for (uint32_t j = 0; j < 16 && w * 16 + j < l; j++) {
-                uint32_t c = base_code(up8(r.seq[w * 16 + j]));     // non-ACGT: stored as 'A'; inside the window it is
+                uint32_t c = base_code(up8(r.seq[pack_src(pl, w * 16 + j)]));     // non-ACGT: stored as 'A'; inside the window it is
                 if (c > 3u) { c = 0; flagged |= (w * 16 + j >= from); }   // flagged, outside it is never looked at
                 v |= c << (2 * j);
             }
@@ -1963,9 +1972,10 @@ F2Q_HD void pack_read(const PackPlan &pl, const RecT<P> &r, uint32_t planar_nw, 
         for (uint32_t j = 0; j < 4; j++) {
             const uint32_t pos = planar_nw ? planar_qpos(w, j) : w * 4 + j;     // planar tiles: transposed groups (fail_word8)
             if (pos >= l) continue;
-            uint32_t q = r.qual[pos];
+            const uint32_t at = planar_nw ? pos : pack_src(pl, pos);
+            uint32_t q = r.qual[at];
             q = (q & 0x80u) ? 0u : q;                               // keep every stored byte 7-bit (SWAR)
-            const uint8_t sc = planar_nw ? (uint8_t)r.seq[pos] : up8(r.seq[pos]);
+            const uint8_t sc = planar_nw ? (uint8_t)r.seq[at] : up8(r.seq[at]);
             if (pos >= from && base_code(sc) > 3u) q |= 0x80u;      // flag bit
             v |= q << (8 * j);
         }

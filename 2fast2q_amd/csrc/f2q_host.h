@@ -455,7 +455,12 @@ inline PackPlan make_plan(const RunDev &run)
         run.n_iter * run.length <= F2Q_REG_MAXLEN) {
         int lo = run.start[0], hi = run.start[0];
         for (int i = 1; i < run.n_iter; i++) { lo = run.start[i] < lo ? run.start[i] : lo; hi = run.start[i] > hi ? run.start[i] : hi; }
-        if (lo >= 0 && hi + run.length <= F2Q_PACK_MAXLEN) { pl.fast_fixed = true; pl.multi = true; pl.from = lo; pl.need = hi + run.length; }
+        if (lo >= 0 && hi + run.length <= F2Q_PACK_MAXLEN) {
+            pl.fast_fixed = true; pl.multi = true;
+            pl.n_win = run.n_iter; pl.win_len = run.length; pl.win_end = hi + run.length;       // only the windows are stored, back to back
+            for (int i = 0; i < run.n_iter; i++) pl.win_start[i] = run.start[i];
+            pl.from = 0; pl.need = run.n_iter * run.length;
+        }
     }
     pl.fast_anchor = !run.fixed && run.n_iter == 1 && run.anchors_packed && run.msu >= 0 && run.msd >= 0 &&
                      run.msu <= 7 && run.msd <= 7 && run.length >= 0 && run.length <= F2Q_ANCHOR_MAXLEN;
@@ -548,6 +553,7 @@ inline int fill_run(const f2q_params &p, RunDev &r, std::string &err)
         if (p.n_start < 1 || p.n_start > F2Q_MAX_ITER) { err = "n_start must be 1..16"; return F2Q_EINVAL; }
         r.fixed = 1; r.n_iter = p.n_start;
         for (int i = 0; i < p.n_start; i++) r.start[i] = p.start[i];
+        r.compact = make_plan(r).multi ? 1 : 0;                   // the packed tiles of a multi-window run hold the windows only
         return F2Q_OK;
     }
     // :543-558

@@ -2180,6 +2180,11 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
     o.all_general = fast ? 0 : 1;
     o.inband_n = c->plan.inband_n ? 1 : 0;
     o.planar_nw = planar ? (R <= 96 ? 3u : R <= 160 ? 5u : 10u) : 0u;
+    if (c->plan.fast_fixed && c->plan.n_win) {                     // several windows: the tiles hold the windows only
+        o.n_win = c->plan.n_win; o.win_len = c->plan.win_len; o.win_end = c->plan.win_end;
+        for (int i = 0; i < c->plan.n_win; i++) o.win_start[i] = c->plan.win_start[i];
+    }
+    const int Rs = o.n_win ? o.n_win * o.win_len : R;               // bases a tile stores per read
     const uint64_t n_tiles = (s->n_reads + F2Q_TILE - 1) / F2Q_TILE;
     const uint64_t n_slots = n_tiles * F2Q_TILE;
     // general-path capacity: everything, or the expected 'N' share with a wide margin
@@ -2189,8 +2194,8 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
     if (gcap == 0) gcap = 1;
     do {
         if (fast) {
-            o.wb = planar ? 2 * o.planar_nw : (uint32_t)((R + 15) / 16);
-            o.wq = planar ? 8 * o.planar_nw : (uint32_t)((R + 3) / 4);
+            o.wb = planar ? 2 * o.planar_nw : (uint32_t)((Rs + 15) / 16);
+            o.wq = planar ? 8 * o.planar_nw : (uint32_t)((Rs + 3) / 4);
             if ((rc = dev_alloc(c, (size_t)n_tiles * o.wb * F2Q_TILE, &o.bases, b->allocs, 0))) break;
             if ((rc = dev_alloc(c, (size_t)n_tiles * o.wq * F2Q_TILE, &o.qual, b->allocs, 0))) break;
             if ((rc = dev_alloc(c, (size_t)n_slots, &o.len, b->allocs))) break;
@@ -2212,7 +2217,7 @@ extern "C" int f2q_synth_create(f2q_ctx *c, const f2q_synth *s, f2q_block **out)
         if (g > gcap) { rc = fail(c, F2Q_ENOMEM, "synthetic general-path capacity exceeded"); break; }
         b->n_general = g;
         if (fast) {
-            b->pb.n_slots = n_slots; b->pb.n_tiles = (uint32_t)n_tiles; b->pb.wb = o.wb; b->pb.wq = o.wq; b->pb.rmax = (uint32_t)R;
+            b->pb.n_slots = n_slots; b->pb.n_tiles = (uint32_t)n_tiles; b->pb.wb = o.wb; b->pb.wq = o.wq; b->pb.rmax = (uint32_t)Rs;
             b->pb.planar_nw = o.planar_nw;
             b->pb.bases = o.bases; b->pb.qual = o.qual; b->pb.len = o.len;
         }

@@ -643,7 +643,9 @@ def test_multi_window_packed_kernel_vs_oracle(P, monkeypatch, miss, starts, leng
         counts, stats = c.read_counts()
     assert list(stats) == o.stats() and list(counts) == o.counts()
     packed = 2 * W * length + len(lib).bit_length() <= 64
-    assert (t["general_reads"] == 0) if packed else (t["fast_reads"] == 0)
+    # (the tiles hold the windows only: a read that ends inside a window goes to the byte-exact kernel)
+    short = sum(len(x) < max(int(v) for v in starts.split(",")) + length for x in fq.split(b"\n")[1::4])
+    assert (t["general_reads"] == short and short > 100) if packed else (t["fast_reads"] == 0)
     monkeypatch.setenv("F2Q_FORCE_GENERAL", "1")
     with P.Counter(features=lib, **kw) as c:
         _, t2 = c.count_block(fq, want_timing=True)
