@@ -536,7 +536,11 @@ __device__ __forceinline__ void lt_count(uint32_t *cnt, uint32_t slot, const Acc
 
 // A20: the window is 20 bases starting at a multiple of 16 (--l 20 with --st 0, 16, ...: the usual guide-counting run):
 // the key needs no shift, every quality row is tested whole, and the table geometry (two 10-base halves) is constant.
-template <int NQ, int NB, bool NEAR, bool A20>
+// MW: a multi-window run (--st a,b[,c,d]) on tiles that hold the windows back to back (PackPlan::n_win) against a library
+// whose features all have one part per window: the compact window is one window of n_iter * length bases, except that
+// the Phred rule is applied part by part -- a read with a failed part has a key of fewer parts, which equals or
+// approaches no feature; only a read whose parts all fail counts as failed (fast2q.py:357-363).
+template <int NQ, int NB, bool NEAR, bool A20, bool MW = false>
 __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDev *__restrict__ runp,
                                                                      const LibDev *__restrict__ libp, PackedBlock pb,
                                                                      Accum acc)
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
         for (uint32_t i = tid; i < F2Q_LT_BUCKETS; i += F2Q_LT_THREADS) cnt[i] = 0;
     }
     __syncthreads();
-    FixedGeom g = fixed_geom(run);
+    FixedGeom g = MW ? fixed_geom_at(0, run.n_iter * run.length, run.thr) : fixed_geom(run);
     if (A20) { g.L = 20; g.nq = 5; g.nb = 2; g.sh = 0; g.qm_first = 0x80808080u; g.qm_last = 0x80808080u; g.kmask = (1ull << 40) - 1ull; }
     const int need = g.st + g.L;
     // the five reference counters of this wave, kept in scalar registers: the per-read verdicts are lane masks already
@@ -588,7 +592,14 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
     };
     auto decide_tile = [&](const Rows &r) {
         uint32_t bad[4] = {0, 0, 0, 0};
-        if (g.add_hi) {
+        bool part_fail[4] = {false, false, false, false};             // MW: some part, but not every part, fails its Phred test
+        if (MW && g.add_hi) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int pv = mw_part_verdict(fixed4_failbits(g, r.q, j), run.n_iter, run.length);
+                bad[j] = pv == 2 ? 1u : 0u; part_fail[j] = pv == 1;
+            }
+        } else if (g.add_hi) {
             if (A20) {
                 // every byte of the five rows is under the window: OR the rows' verdicts, mask once
 #pragma unroll
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
                 const bool live = l != F2Q_LEN_SKIP, qf = live && bad[j] != 0u;
                 // a read that ends inside the window gives a shorter key (:354); every feature is L long, so it can equal
                 // or approach none (:683); its bytes past the end are stored as 0 and never fail the Phred test
-                cand[a] = live && !qf && (int)(l & F2Q_LEN_MASK) >= need;
+                cand[a] = live && !qf && (int)(l & F2Q_LEN_MASK) >= need && !(MW && part_fail[j]);
                 w_reads += (uint32_t)__popcll(__ballot(live));
                 w_qfail += (uint32_t)__popcll(__ballot(qf));
                 forced[a] = 0;

@@ -1169,6 +1169,31 @@ F2Q_HD uint32_t fixed4_flags(const FixedGeom &g, const U4 (&q)[QR], int j)
     return (uint32_t)(bits >> (g.st & 3));
 }
 
+// Phred verdict per window base of read j of a lane (bit i set: base i of the window fails) -- the multi-window form of
+// the kernels tests each part of the compact window by itself (a failed part is omitted, fast2q.py:357-360)
+template <int QR>
+F2Q_HD uint32_t fixed4_failbits(const FixedGeom &g, const U4 (&q)[QR], int j)
+{
+    uint64_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < QR; r++) {
+        if (r < g.nq) {
+            const uint32_t m = (r == 0) ? g.qm_first : (r == g.nq - 1) ? g.qm_last : 0x80808080u;
+            const uint32_t f = qfail4(u4get(q[r], j) & 0x7F7F7F7Fu, g.add_lo, g.add_hi, m) >> 7;
+            bits |= (uint64_t)((f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu) << (4 * r);
+        }
+    }
+    return (uint32_t)(bits >> (g.st & 3));
+}
+// ... and what they say about a read of n_parts windows of part_len bases: 0 = every part passes, 1 = some part fails
+// (the key has fewer parts: in a library of n_parts-part features it can equal or approach none), 2 = every part fails
+F2Q_HD int mw_part_verdict(uint32_t failbits, int n_parts, int part_len)
+{
+    int failed = 0;
+    for (int w = 0; w < n_parts; w++) failed += (failbits >> (w * part_len)) & ((1u << part_len) - 1u) ? 1 : 0;
+    return failed == 0 ? 0 : failed == n_parts ? 2 : 1;
+}
+
 // Extract+Count with a fixed window: the single-word key of read j of a lane (l = its length word).  The window is
 // clipped to the read like a Python slice (fast2q.py:354); an 'N' inside it travels as a flag bit and is spelt into the
 // word (ec64_word) -- the packer passes only reads whose window has a single-word form (read_is_clean).

@@ -402,7 +402,13 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
         if (!by_len[packed_len].empty() && ix.pk.len == 0) mw_ok = false;
         ix.mw_ok = mw_ok ? 1u : 0u;
     }
-    build_lt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss);
+    {
+        // a multi-window run whose features ALL have as many parts as the run has windows: the LDS tables index the joined
+        // keys (the compact window of the tiles is mw_windows * packed_len bases long)
+        bool mw_lt = multi && mw_ok && by_len[packed_len].empty() && by_parts[mw_windows].size() == (size_t)n;
+        if (mw_lt) build_lt(ix, by_parts[mw_windows], mw_windows * packed_len, miss);
+        else build_lt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN && !multi) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss);
+    }
     build_pt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss, ix.pt_force_parts);
     build_gk(ix, miss);
     ix.n_irregular = (uint32_t)ix.irr_ids.size();

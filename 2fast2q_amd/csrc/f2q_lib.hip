@@ -778,7 +778,40 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         const bool lds = c->lib_h.n_features <= F2Q_HIST_MAX;
         const bool v2 = !c->force_v1 && c->lib_h.pk.len == (uint32_t)c->run_h.length && c->lib_h.pk.len > 0 &&
                         c->lib_h.n_irregular == 0;
-        if (c->plan.multi) {
+        const int mw_total = c->run_h.n_iter * c->run_h.length;
+        const bool mw_lt = c->plan.multi && lds && !c->no_lt && c->lib_h.lt.ok && c->lib_h.lt.len == (uint32_t)mw_total && c->run_h.miss <= 1 &&
+                           pb.len != nullptr && (uint32_t)((mw_total + 3) / 4) <= pb.wq && (uint32_t)((mw_total + 15) / 16) <= pb.wb;
+        if (mw_lt) {
+            // several windows per read, every feature with one part per window: the joined keys on the library-in-LDS kernel
+            // (the tiles hold the windows back to back: one window of n_iter * length bases, Phred rule per part)
+            c->last_path = F2Q_PATH_MULTI_LDS;
+            const uint32_t wgs = (pb.n_tiles + F2Q_LT_WAVES - 1) / F2Q_LT_WAVES;
+            const uint32_t grid = std::min<uint32_t>(wgs, (uint32_t)c->n_cu);
+            const bool near = c->run_h.miss > 0;
+            const size_t shmem = ((near ? 2u : 1u) * (size_t)F2Q_LT_SLOTS + F2Q_LT_BUCKETS) * 4;
+            const FixedGeom fg = fixed_geom_at(0, mw_total, c->run_h.thr);
+            const bool spec52 = !c->force_generic && fg.nq == 5 && fg.nb == 2 && c->run_h.thr >= 33;
+            const bool a20 = spec52 && mw_total == 20;              // (two 10-base or four 5-base windows: the usual 20-base geometry)
+            auto kern = near ? (a20 ? k_count_fixed4_lds<5, 2, true, true, true> : spec52 ? k_count_fixed4_lds<5, 2, true, false, true> : k_count_fixed4_lds<0, 0, true, false, true>)
+                             : (a20 ? k_count_fixed4_lds<5, 2, false, true, true> : spec52 ? k_count_fixed4_lds<5, 2, false, false, true> : k_count_fixed4_lds<0, 0, false, false, true>);
+            const uint32_t nf_ = c->lib_h.n_features;
+            const size_t need = (size_t)grid * nf_;
+            if (need > c->slab_n || (size_t)grid > c->stat_slab_n) {
+                if (c->slab_d) (void)hipFree(c->slab_d);
+                if (c->stat_slab_d) (void)hipFree(c->stat_slab_d);
+                c->slab_d = nullptr; c->slab_n = 0; c->stat_slab_d = nullptr; c->stat_slab_n = 0;
+                HIPC(c, hipMalloc((void **)&c->slab_d, std::max<size_t>(need, 1) * sizeof(uint32_t)));
+                HIPC(c, hipMalloc((void **)&c->stat_slab_d, (size_t)grid * 8 * sizeof(unsigned long long)));
+                c->slab_n = need; c->stat_slab_n = grid;
+            }
+            acc.slab = c->slab_d; acc.stat_slab = c->stat_slab_d;
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(F2Q_LT_THREADS), shmem, c->stream, c->run_d, c->lib_d, pb, acc);
+            HIPC(c, hipGetLastError());
+            hipLaunchKernelGGL(k_reduce_slabs, dim3((nf_ + 63) / 64, F2Q_RED_SPLIT), dim3(256), 0, c->stream,
+                               c->slab_d, grid, nf_, acc.counts, c->stat_slab_d, grid, acc.stats);
+            launches++;
+        } else if (c->plan.multi) {
             // several windows per read (--st a,b,...): k-part keys against the k-part features
             c->last_path = F2Q_PATH_MULTI;
             const uint32_t wgs = (pb.n_tiles + F2Q_V2_WAVES - 1) / F2Q_V2_WAVES;

@@ -104,7 +104,8 @@ enum {
     F2Q_PATH_ANCHOR = 6,                 /* k_count_anchor                                        */
     F2Q_PATH_ANCHOR_LDS = 7,             /* k_count_anchor_lt                                     */
     F2Q_PATH_PAIRS = 8,                  /* k_count_anchor_pairs                                  */
-    F2Q_PATH_EXTRACT = 9                 /* the Extract+Count kernels                             */
+    F2Q_PATH_EXTRACT = 9,                /* the Extract+Count kernels                             */
+    F2Q_PATH_MULTI_LDS = 10              /* k_count_fixed4_lds<.., MW>: several windows, joined keys in the LDS tables */
 };
 
 typedef struct f2q_block f2q_block;      /* a device-resident block of reads (opaque)           */

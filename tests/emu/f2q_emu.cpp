@@ -258,6 +258,53 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
             }
     } else {
     const bool v2 = e->use_v2 && e->lib.pk.len == (uint32_t)e->run.length && e->lib.pk.len > 0 && e->lib.n_irregular == 0;
+    const int mw_total = e->run.n_iter * e->run.length;
+    if (e->plan.multi && e->use_lt && e->lib.lt.ok && e->lib.lt.len == (uint32_t)mw_total && e->run.miss <= 1) {
+        // k_count_fixed4_lds<.., MW>'s per-lane sequence: the compact window as ONE window, the Phred rule per part, the
+        // joined key against the LDS tables of the library's n_iter-part features
+        const FixedGeom g = fixed_geom_at(0, mw_total, e->run.thr);
+        const LtDesc &lt = e->lib.lt;
+        for (uint32_t t = 0; t < hp.n_tiles; t++)
+            for (uint32_t lane = 0; lane < 64; lane++) {
+                U4 b[F2Q_MAXBROWS], qr[F2Q_MAXQROWS];
+                const uint32_t *qp = pb.qual + ((uint64_t)t * pb.wq) * F2Q_TILE + 4 * lane;
+                const uint32_t *bp = pb.bases + ((uint64_t)t * pb.wb) * F2Q_TILE + 4 * lane;
+                for (int r = 0; r < F2Q_MAXBROWS; r++) {
+                    uint32_t row = g.bw0 + (r < g.nb ? r : (g.nb > 0 ? g.nb - 1 : 0));
+                    row = row < pb.wb ? row : pb.wb - 1;
+                    const uint32_t *p = bp + (uint64_t)row * F2Q_TILE; b[r] = U4{p[0], p[1], p[2], p[3]};
+                }
+                for (int r = 0; r < F2Q_MAXQROWS; r++) {
+                    uint32_t row = g.qw0 + (r < g.nq ? r : (g.nq > 0 ? g.nq - 1 : 0));
+                    row = row < pb.wq ? row : pb.wq - 1;
+                    const uint32_t *p = qp + (uint64_t)row * F2Q_TILE; qr[r] = U4{p[0], p[1], p[2], p[3]};
+                }
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t l = pb.len[(uint64_t)t * F2Q_TILE + 4 * lane + j];
+                    if (l == F2Q_LEN_SKIP) continue;
+                    acc.stats[0]++; e->v2_reads++; e->lt_reads++;
+                    const int pv = g.add_hi ? mw_part_verdict(fixed4_failbits(g, qr, j), e->run.n_iter, e->run.length) : 0;
+                    if (pv == 2) { acc.stats[R_QFAIL]++; continue; }
+                    if (pv == 1 || (int)(l & F2Q_LEN_MASK) < mw_total) { acc.stats[R_NONALIGNED]++; continue; }
+                    const uint32_t forced = (l & F2Q_LEN_FLAG) ? fixed4_flags(g, qr, j) : 0u;
+                    const LtProbe q = lt_probe(lt, fixed4_key(g, b, j));
+                    U2 en[4];
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t *tb = lt.tags + (size_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q.b[k];
+                        en[k] = U2{tb[0], tb[1]};
+                    }
+                    auto rd0 = [&](uint32_t bk) { return U2{lt.tags[2u * bk], lt.tags[2u * bk + 1u]}; };
+                    int res; uint32_t slot = 0;
+                    if (forced && (e->run.miss == 0 || __builtin_popcount(forced) > e->run.miss)) res = R_NONALIGNED;
+                    else {
+                        const LtVerdict v = e->run.miss > 0 ? lt_decide<true>(lt, q, en, forced, rd0) : lt_decide<false>(lt, q, en, forced, rd0);
+                        res = v.perfect ? R_PERFECT : v.imperfect ? R_IMPERFECT : R_NONALIGNED; slot = v.slot;
+                    }
+                    if (res == R_PERFECT || res == R_IMPERFECT) acc.counts[lt.feat_of[slot]]++;
+                    acc.stats[res]++;
+                }
+            }
+    } else
     if (e->plan.multi) {
         // k_count_multi4's per-lane sequence: windows one after another, parts that pass concatenated, k-part tables
         const int W = e->run.n_iter, L = e->run.length;

@@ -654,6 +654,32 @@ def test_multi_window_packed_kernel_vs_oracle(P, monkeypatch, miss, starts, leng
     assert t2["fast_reads"] == 0 and list(stats2) == list(stats) and list(counts2) == list(counts)
 
 
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("starts,length,rl", [("0,10", 10, 40), ("3,40,21", 6, 60), ("5,100", 8, 150), ("0,7,14,21", 5, 31), ("60,2", 9, 75), ("0,20", 7, 30)])
+def test_multi_window_lds_kernel_vs_oracle(P, monkeypatch, miss, starts, length, rl):
+    """k_count_fixed4_lds<.., MW>: several windows (also far apart: the tiles hold the windows back to back), every feature
+    with one part per window, joined keys in the LDS tables, Phred rule part by part -- against the oracle, the k-part
+    packed tables (k_count_multi4, F2Q_NO_LT=1) and the byte-exact general kernel"""
+    from test_lane_logic_cpu import multi_window_uniform_case
+    lib, fq = multi_window_uniform_case(starts, length, rl, n_reads=40000, seed=1)
+    kw = dict(miss=miss, length=length, start=starts)
+    o = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    short = sum(len(x) < max(int(v) for v in starts.split(",")) + length for x in fq.split(b"\n")[1::4])
+    res = []
+    for env in ({}, {"F2Q_NO_LT": "1"}, {"F2Q_FORCE_GENERAL": "1"}, {"F2Q_HOST_PACK": "1"}, {"F2Q_GENERIC": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with P.Counter(features=lib, **kw) as c:
+            _, t = c.count_block(fq, want_timing=True)
+            counts, stats = c.read_counts()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert list(stats) == o.stats() and list(counts) == o.counts(), env
+        res.append((t["path"], t["general_reads"]))
+    assert [r[0] for r in res[:2]] == [10, 5] and res[3][0] == 10 and res[4][0] == 10       # F2Q_PATH_MULTI_LDS, F2Q_PATH_MULTI
+    assert res[0][1] == short and res[1][1] == short and res[2][1] == 40000
+
+
 @pytest.mark.parametrize("miss", [0, 1, 3])
 @pytest.mark.parametrize("glen", [12, 40])
 def test_general_key_index_kernel_vs_oracle(P, miss, glen):
@@ -708,6 +734,15 @@ def test_two_window_full_size(P, monkeypatch):
         c2, s2 = c.read_counts()
         blk.free()
     assert t2["general_reads"] == 0 and s2[0] == 50_000_000 and s2[0] == sum(s2[1:]) and c2.sum() == s2[1] + s2[2]
+    assert t2["path"] == 10                                      # the joined keys on the library-in-LDS kernel
+    monkeypatch.setenv("F2Q_NO_LT", "1")                         # ... and on the k-part packed tables (k_count_multi4)
+    with P.Counter(features=lib2, **kw) as c:
+        blk = c.synth_create(guides=guides, **spec)
+        t3 = c.count_resident(blk)
+        c3, s3 = c.read_counts()
+        blk.free()
+    monkeypatch.delenv("F2Q_NO_LT")
+    assert t3["path"] == 5 and list(c3) == list(c2) and list(s3) == list(s2)
     c1, s1, _, _ = _full(P, monkeypatch, {}, guides, spec, miss=1, phred=30, length=20, start="0")
     # both parts pass <=> the 20-base window passes, and then the verdicts are the same (the ':' sits between the halves);
     # a read with one failed part yields a one-part key, and the library has no one-part feature

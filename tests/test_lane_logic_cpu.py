@@ -196,6 +196,70 @@ def test_multi_window_packed_logic_vs_oracle(miss, starts, length, rl):
     assert s2 == o2.stats() and c2 == o2.counts() and fast2 == 0 and gen2 == 5000
 
 
+def multi_window_uniform_case(starts, length, rl, n_feat=200, n_reads=6000, seed=0):
+    """a library whose features all have one part per window (dual-guide pairs), reads with the parts planted at the
+    windows: substitutions, N, low-quality parts, some reads that end inside a window"""
+    import random
+    rng = random.Random(1000 * len(starts) + length + seed)
+    st = [int(x) for x in starts.split(",")]
+    base = synth.make_library(len(st) * n_feat, length, 60 + length)            # every part belongs to one feature (a pair library
+    lib = [":".join(base[len(st) * f + w] for w in range(len(st))) for f in range(n_feat)]   # of unrelated guides)
+    lines = []
+    for i in range(n_reads):
+        n = rl if rng.random() > 0.04 else rng.randint(0, rl - 1)
+        seq = [rng.choice("ACGT") for _ in range(rl)]
+        feat = rng.choice(lib).split(":")
+        for w, s0 in enumerate(st):
+            part = feat[w] if rng.random() < 0.9 else rng.choice(base)
+            seq[s0:s0 + length] = list(part)[: max(0, rl - s0)]
+        for _ in range(rng.choice([0, 0, 1, 1, 2])):
+            p = rng.randrange(rl); seq[p] = rng.choice("ACGTN")
+        q = ["I"] * rl
+        for _ in range(rng.choice([0, 0, 0, 1, 2])):
+            q[rng.randrange(rl)] = rng.choice("#5>=")
+        lines.append(f"@r{i}\n{''.join(seq)[:n]}\n+\n{''.join(q)[:n]}\n")
+    return lib, "".join(lines).encode()
+
+
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("starts,length,rl", [("0,10", 10, 40), ("3,40,21", 6, 60), ("5,100", 8, 150), ("0,7,14,21", 5, 31), ("60,2", 9, 75), ("0,20", 7, 30)])
+def test_multi_window_lds_tables_vs_oracle(miss, starts, length, rl):
+    """several windows, every feature with one part per window (dual-guide libraries): the joined keys go through the
+    library-in-LDS logic (k_count_fixed4_lds<.., MW>: the tiles hold the windows back to back, the Phred rule is applied
+    part by part) -- against the oracle and against the k-part packed tables (k_count_multi4's logic)"""
+    lib, fq = multi_window_uniform_case(starts, length, rl)
+    kw = dict(miss=miss, length=length, start=starts)
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    e = Emu(features=lib, **kw)
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats() and counts == o.counts()
+    short = sum(len(x) < max(int(v) for v in starts.split(",")) + length for x in fq.split(b"\n")[1::4])
+    assert gen == short and e.lt_reads() == 6000 - short and stats[2] > 0 or miss == 0
+    assert e.lt_ok()
+    e2 = Emu(features=lib, lt=False, **kw)
+    e2.count_block(fq)
+    assert e2.read()[:2] == (counts, stats) and e2.lt_reads() == 0
+    # a library that also holds a feature of fewer parts keeps to the k-part tables; so does a combinatorial library (one
+    # guide paired with many partners: more than four features share a half, the LDS tables cannot be built)
+    parts0 = [f.split(":") for f in lib[:12]]
+    lib4 = lib + [":".join([parts0[0][0]] + p[1:]) for p in parts0[1:8]]
+    e4 = Emu(features=lib4, **kw)
+    e4.count_block(fq)
+    o4 = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib4)], **kw)
+    o4.count_fastq(fq)
+    assert e4.read()[:2] == (o4.counts(), o4.stats())
+    if starts.count(",") == 1:                       # two windows: a part IS a half of the joined key
+        assert e4.lt_reads() == 0 and not e4.lt_ok()
+    lib3 = lib + [lib[0].split(":")[0]]
+    e3 = Emu(features=lib3, **kw)
+    e3.count_block(fq)
+    o3 = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib3)], **kw)
+    o3.count_fastq(fq)
+    assert e3.read()[:2] == (o3.counts(), o3.stats()) and e3.lt_reads() == 0
+
+
 def test_lds_tables_applicability():
     """built only for uniform ACGT libraries of 14..21-base features searched with --m <= 1 that fit the tables"""
     g20 = synth.make_library(500, 20, 1)
