@@ -635,7 +635,9 @@ __global__ __launch_bounds__(F2Q_LT_THREADS) void k_count_fixed4_lds(const RunDe
                 w_qfail += (uint32_t)__popcll(__ballot(qf));
                 forced[a] = 0;
                 if ((l & F2Q_LEN_FLAG) && cand[a]) forced[a] = fixed4_flags(g, r.q, j);   // non-ACGT symbols in the window (rare)
-                q[a] = lt_probe(lt, fixed4_key(g, r.b, j));
+                uint64_t key = fixed4_key(g, r.b, j);
+                if (MW && lt.mix) { key = mw_mix(key, lt.mix); if (forced[a]) forced[a] = mw_mix_mask(forced[a], lt.mix); }
+                q[a] = lt_probe(lt, key);
 #pragma unroll
                 for (int k = 0; k < (NEAR ? 4 : 2); k++) e[a][k] = lds_u2(tg + (uint32_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q[a].b[k]);
                 if (!NEAR) { e[a][2] = U2{F2Q_LT_EMPTY, F2Q_LT_EMPTY}; e[a][3] = e[a][2]; }

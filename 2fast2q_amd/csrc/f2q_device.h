@@ -96,6 +96,7 @@ struct LtDesc {
     uint32_t ok;                       // 1: tables built for this library
     uint32_t len;                      // feature length L
     uint32_t hb0, hb1;                 // bits of half 0 (bases [0, L/2)) and half 1 (the rest)
+    uint32_t mix, pad_;                // > 0: two-window runs, keys are looked up as mw_mix(key, mix) (mix = bases per window)
     const uint32_t *tags;              // [2][F2Q_LT_SLOTS]: table t is bucketed by half t and stores the other half in its tags
     const uint16_t *slot_of;           // [n_features] table-0 slot of a feature = its counter in the LDS histogram
     const uint32_t *feat_of;           // [F2Q_LT_SLOTS] feature of a table-0 slot (unused slots: 0)
@@ -1168,6 +1169,21 @@ F2Q_HD uint32_t fixed4_flags(const FixedGeom &g, const U4 (&q)[QR], int j)
     }
     return (uint32_t)(bits >> (g.st & 3));
 }
+
+// Two windows A, B of L bases each: the joined key with its middle quarters swapped, [A_lo B_lo A_hi B_hi] (A_lo = the
+// first L/2 bases of A).  The LDS tables bucket by the halves of the key they are given; with the plain joined key a half
+// IS a window, and in a combinatorial pair library (one guide with many partners) more features share a half than a
+// bucket holds.  Mixed, two features share a half only if they agree on half of BOTH guides.  A permutation of the
+// bases changes no Hamming distance; the forced-mismatch mask is permuted the same way (unit = bits per base: 2 / 1).
+F2Q_HD uint64_t mw_mix_bits(uint64_t x, uint32_t L, uint32_t unit)
+{
+    const uint32_t a = (L / 2u) * unit, b = (L - L / 2u) * unit, w = L * unit;        // bits of A_lo (= B_lo), A_hi (= B_hi), a window
+    const uint64_t alo = x & ((1ull << a) - 1ull), ahi = (x >> a) & ((1ull << b) - 1ull);
+    const uint64_t blo = (x >> w) & ((1ull << a) - 1ull), bhi = (x >> (w + a)) & ((1ull << b) - 1ull);
+    return alo | (blo << a) | (ahi << (2u * a)) | (bhi << (2u * a + b));
+}
+F2Q_HD uint64_t mw_mix(uint64_t key, uint32_t L) { return mw_mix_bits(key, L, 2u); }
+F2Q_HD uint32_t mw_mix_mask(uint32_t forced, uint32_t L) { return (uint32_t)mw_mix_bits(forced, L, 1u); }
 
 // Phred verdict per window base of read j of a lane (bit i set: base i of the window fails) -- the multi-window form of
 // the kernels tests each part of the compact window by itself (a failed part is omitted, fast2q.py:357-360)

@@ -406,7 +406,18 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
         // a multi-window run whose features ALL have as many parts as the run has windows: the LDS tables index the joined
         // keys (the compact window of the tiles is mw_windows * packed_len bases long)
         bool mw_lt = multi && mw_ok && by_len[packed_len].empty() && by_parts[mw_windows].size() == (size_t)n;
-        if (mw_lt) build_lt(ix, by_parts[mw_windows], mw_windows * packed_len, miss);
+        if (mw_lt) {
+            build_lt(ix, by_parts[mw_windows], mw_windows * packed_len, miss);
+            if (!ix.lt.ok && mw_windows == 2) {
+                // two windows and features that share whole windows (a combinatorial pair library): the tables are built
+                // on, and asked with, the mixed form of the joined keys (mw_mix: a dozen instructions per read more)
+                std::vector<uint64_t> plain = ix.key2;
+                for (uint32_t f : by_parts[2]) ix.key2[f] = mw_mix(plain[f], (uint32_t)packed_len);
+                build_lt(ix, by_parts[2], 2 * packed_len, miss);
+                ix.key2.swap(plain);
+                ix.lt.mix = (uint32_t)packed_len;
+            }
+        }
         else build_lt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN && !multi) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss);
     }
     build_pt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss, ix.pt_force_parts);

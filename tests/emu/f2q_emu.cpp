@@ -286,8 +286,10 @@ size_t emu_count_block(void *h, const uint8_t *buf, size_t n)
                     const int pv = g.add_hi ? mw_part_verdict(fixed4_failbits(g, qr, j), e->run.n_iter, e->run.length) : 0;
                     if (pv == 2) { acc.stats[R_QFAIL]++; continue; }
                     if (pv == 1 || (int)(l & F2Q_LEN_MASK) < mw_total) { acc.stats[R_NONALIGNED]++; continue; }
-                    const uint32_t forced = (l & F2Q_LEN_FLAG) ? fixed4_flags(g, qr, j) : 0u;
-                    const LtProbe q = lt_probe(lt, fixed4_key(g, b, j));
+                    uint32_t forced = (l & F2Q_LEN_FLAG) ? fixed4_flags(g, qr, j) : 0u;
+                    uint64_t key = fixed4_key(g, b, j);
+                    if (lt.mix) { key = mw_mix(key, lt.mix); forced = mw_mix_mask(forced, lt.mix); }
+                    const LtProbe q = lt_probe(lt, key);
                     U2 en[4];
                     for (int k = 0; k < 4; k++) {
                         const uint32_t *tb = lt.tags + (size_t)(k >> 1) * F2Q_LT_SLOTS + 2u * q.b[k];

@@ -656,12 +656,17 @@ def test_multi_window_packed_kernel_vs_oracle(P, monkeypatch, miss, starts, leng
 
 @pytest.mark.parametrize("miss", [0, 1])
 @pytest.mark.parametrize("starts,length,rl", [("0,10", 10, 40), ("3,40,21", 6, 60), ("5,100", 8, 150), ("0,7,14,21", 5, 31), ("60,2", 9, 75), ("0,20", 7, 30)])
-def test_multi_window_lds_kernel_vs_oracle(P, monkeypatch, miss, starts, length, rl):
+@pytest.mark.parametrize("combo", [False, True], ids=["pairs", "combinatorial"])
+def test_multi_window_lds_kernel_vs_oracle(P, monkeypatch, miss, starts, length, rl, combo):
     """k_count_fixed4_lds<.., MW>: several windows (also far apart: the tiles hold the windows back to back), every feature
     with one part per window, joined keys in the LDS tables, Phred rule part by part -- against the oracle, the k-part
     packed tables (k_count_multi4, F2Q_NO_LT=1) and the byte-exact general kernel"""
     from test_lane_logic_cpu import multi_window_uniform_case
     lib, fq = multi_window_uniform_case(starts, length, rl, n_reads=40000, seed=1)
+    if combo:            # one guide with many partners: two-window keys are looked up in their mixed form (mw_mix)
+        parts0 = [f.split(":") for f in lib[:60]]
+        lib = list(dict.fromkeys(lib + [":".join([parts0[i % 6][0]] + p[1:]) for i, p in enumerate(parts0[6:60])] +
+                                 [":".join(p[:-1] + [parts0[i % 4][-1]]) for i, p in enumerate(parts0[4:50])]))
     kw = dict(miss=miss, length=length, start=starts)
     o = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
     short = sum(len(x) < max(int(v) for v in starts.split(",")) + length for x in fq.split(b"\n")[1::4])
