@@ -12,14 +12,76 @@
 // out-of-range access.  tests/test_reader_cpu.py checks it against zlib on random, degenerate and damaged streams.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace f2qz {
 
-// CRC-32 of gzip (reflected 0xEDB88320), slicing-by-16: 16 table look-ups per 16 input bytes.  zlib 1.2.11's crc32
-// runs at ~0.7 GB/s per thread on the test box, which made the checksum a third of a BGZF worker's time.
+#if defined(__x86_64__)
+// CRC-32 of gzip by carry-less multiplication (Gopal et al., "Fast CRC computation for generic polynomials using
+// PCLMULQDQ", Intel 2009): four 128-bit lanes folded 64 bytes at a time, then down to 32 bits by Barrett reduction.
+// Works on the raw register value (callers complement before and after); n >= 64 and a multiple of 16.
+__attribute__((target("pclmul,sse4.1"))) static inline uint32_t crc32_fold(const uint8_t *buf, size_t n, uint32_t crc)
+{
+    static const uint64_t __attribute__((aligned(16))) k1k2[] = {0x0154442bd4ull, 0x01c6e41596ull};     // x^(4*128+32), x^(4*128-32) mod P
+    static const uint64_t __attribute__((aligned(16))) k3k4[] = {0x01751997d0ull, 0x00ccaa009eull};     // x^(128+32), x^(128-32) mod P
+    static const uint64_t __attribute__((aligned(16))) k5k0[] = {0x0163cd6124ull, 0x0000000000ull};     // x^64 mod P
+    static const uint64_t __attribute__((aligned(16))) poly[] = {0x01db710641ull, 0x01f7011641ull};     // P, floor(x^64 / P)
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i *)k1k2);
+    buf += 64; n -= 64;
+    while (n >= 64) {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; n -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i *)k3k4);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (n >= 16) {
+        x2 = _mm_loadu_si128((const __m128i *)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; n -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i *)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i *)poly);
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+
+// CRC-32 of gzip (reflected 0xEDB88320): carry-less multiplication where the CPU has it, else slicing-by-16 (16 table
+// look-ups per 16 input bytes).  zlib 1.2.11's crc32 runs at ~0.7 GB/s per thread on the test box, which made the
+// checksum a third of a BGZF worker's time.
 struct Crc32 {
     uint32_t t[16][256];
+    bool clmul = false;
     Crc32()
     {
         for (uint32_t i = 0; i < 256; i++) {
@@ -29,11 +91,26 @@ struct Crc32 {
         }
         for (int s = 1; s < 16; s++)
             for (uint32_t i = 0; i < 256; i++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFFu];
+#if defined(__x86_64__)
+        const char *e = getenv("F2Q_NO_CLMUL");
+        clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !(e && e[0] == '1');
+        if (clmul) {                                    // (checked once against the tables: a wrong constant must not pass silently)
+            uint8_t probe[211];
+            for (size_t i = 0; i < sizeof probe; i++) probe[i] = (uint8_t)(i * 37u + 11u);
+            clmul = false;
+            const uint32_t want = update(0x1234u, probe, sizeof probe);
+            clmul = true;
+            if (update(0x1234u, probe, sizeof probe) != want) clmul = false;
+        }
+#endif
     }
     // crc = 0 for a new message; the value of the bytes so far to continue one (same convention as zlib)
     uint32_t update(uint32_t crc, const uint8_t *p, size_t n) const
     {
         crc = ~crc;
+#if defined(__x86_64__)
+        if (clmul && n >= 64) { const size_t k = n & ~(size_t)15; crc = crc32_fold(p, k, crc); p += k; n -= k; }
+#endif
         while (n >= 16) {
             uint64_t a, b;
             memcpy(&a, p, 8); memcpy(&b, p + 8, 8);

@@ -54,7 +54,8 @@ struct TextSource {
     int n_threads = 1;
     // BGZF state
     std::vector<uint8_t> cbuf;                  // compressed bytes not yet inflated
-    size_t cpos = 0;                            // first unconsumed byte of cbuf
+    size_t cpos = 0;                            // first unconsumed byte of cbuf (mapped files: of the file)
+    const uint8_t *bmap = nullptr; size_t bmap_len = 0;   // the whole file, memory-mapped: no read-ahead copy, the workers fault their own pages in
     bool c_eof = false;
     std::vector<uint8_t> spill;                 // a member larger than the caller's remaining room
     size_t spill_pos = 0;
@@ -90,7 +91,15 @@ struct TextSource {
         if (regular) { ssize_t r = pread(fd, head, sizeof head, 0); got = r > 0 ? (size_t)r : 0; }
         if (got >= 2 && head[0] == 0x1f && head[1] == 0x8b) {
             uint32_t bsize;
-            if (bgzf_header(head, got, bsize)) { kind = BGZF; return 0; }
+            if (bgzf_header(head, got, bsize)) {
+                kind = BGZF;
+                const char *nm = getenv("F2Q_NO_MMAP");
+                if (file_size > 0 && !(nm && nm[0] == '1')) {
+                    void *m = mmap(nullptr, (size_t)file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                    if (m != MAP_FAILED) { bmap = (const uint8_t *)m; bmap_len = (size_t)file_size; file_pos = file_size; c_eof = true; }
+                }
+                return 0;
+            }
             return open_gzip(0, err);
         }
         if (!regular) {                                   // pipes cannot be sniffed: go by the name, like upstream (:567)
@@ -105,6 +114,7 @@ struct TextSource {
     {
         if (zs_live) { inflateEnd(&zs); zs_live = false; }
         if (zmap) { munmap(const_cast<uint8_t *>(zmap), zmap_len); zmap = nullptr; zmap_len = 0; }
+        if (bmap) { munmap(const_cast<uint8_t *>(bmap), bmap_len); bmap = nullptr; bmap_len = 0; }
         delete infl; infl = nullptr; zoff = 0;
         delete par; par = nullptr; par_member = false;
         for (auto *w : worker_infl) delete w;
@@ -139,7 +149,9 @@ struct TextSource {
     bool seek_bgzf(uint64_t off)
     {
         if (kind != BGZF || !regular) return false;
-        file_pos = off; cbuf.clear(); cpos = 0; c_eof = false; spill.clear(); spill_pos = 0; bad = false; done = false;
+        if (bmap) { cpos = (size_t)std::min<uint64_t>(off, bmap_len); file_pos = file_size; c_eof = true; }
+        else { file_pos = off; cbuf.clear(); cpos = 0; c_eof = false; }
+        spill.clear(); spill_pos = 0; bad = false; done = false;
         return true;
     }
     // BGZF regular files: compressed offset and text bytes of every member, in file order.  false: some member is not
@@ -398,7 +410,7 @@ private:
 
     bool fill_cbuf(size_t want_more)
     {
-        if (c_eof) return false;
+        if (c_eof || bmap) return false;
         const size_t old = cbuf.size();
         cbuf.resize(old + want_more);
         size_t n = 0;
@@ -455,39 +467,42 @@ private:
             return n;
         }
         if (bad) return 0;
-        if (cpos > 0) { cbuf.erase(cbuf.begin(), cbuf.begin() + (ptrdiff_t)cpos); cpos = 0; }   // offsets below index cbuf: compact only here
+        const bool mapped = bmap != nullptr;
+        auto CD = [&]() -> const uint8_t * { return mapped ? bmap : cbuf.data(); };     // the compressed bytes at hand (a mapped file: all of it)
+        auto CN = [&]() -> size_t { return mapped ? bmap_len : cbuf.size(); };
+        if (!mapped && cpos > 0) { cbuf.erase(cbuf.begin(), cbuf.begin() + (ptrdiff_t)cpos); cpos = 0; }   // offsets below index cbuf: compact only here
         std::vector<Member> ms;
         size_t scan = cpos, o_off = 0;
         bool foreign = false;
         for (;;) {
-            if (cbuf.size() - scan < 18) {
+            if (CN() - scan < 18) {
                 if (!fill_cbuf((size_t)32 << 20)) {
-                    if (cbuf.size() - scan > 0) bad = true;       // a few stray bytes: cut-off header
+                    if (CN() - scan > 0) bad = true;       // a few stray bytes: cut-off header
                     break;
                 }
                 continue;
             }
             uint32_t bsize;
-            const uint8_t *h = cbuf.data() + scan;
+            const uint8_t *h = CD() + scan;
             const uint32_t xlen = h[10] | (h[11] << 8);
-            if (cbuf.size() - scan < 12 + (size_t)xlen && !c_eof) { fill_cbuf((size_t)32 << 20); continue; }
-            if (!bgzf_header(h, cbuf.size() - scan, bsize)) {
+            if (CN() - scan < 12 + (size_t)xlen && !c_eof) { fill_cbuf((size_t)32 << 20); continue; }
+            if (!bgzf_header(h, CN() - scan, bsize)) {
                 if (h[0] == 0x1f && h[1] == 0x8b) foreign = true; else bad = true;     // ordinary gzip member / garbage
                 break;
             }
-            if (cbuf.size() - scan < bsize) {
+            if (CN() - scan < bsize) {
                 if (!fill_cbuf((size_t)32 << 20)) { bad = true; break; }               // member cut off
                 continue;
             }
             if (bsize < 12 + xlen + 8) { bad = true; break; }
-            const uint8_t *tail = cbuf.data() + scan + bsize - 4;
+            const uint8_t *tail = CD() + scan + bsize - 4;
             const uint32_t isize = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
             if (o_off + isize > cap) {
                 if (!ms.empty()) break;                           // next call
                 // one member larger than the room offered: inflate aside and hand out in pieces
                 Member m{scan, bsize, 12 + xlen, isize, 0};
                 spill.assign(isize, 0); spill_pos = 0;
-                if (!inflate_member(cbuf.data(), m, spill.data(), worker_decoder(0))) { spill.clear(); bad = true; return 0; }
+                if (!inflate_member(CD(), m, spill.data(), worker_decoder(0))) { spill.clear(); bad = true; return 0; }
                 cpos = scan + bsize;
                 return read_bgzf(dst, cap);
             }
@@ -505,7 +520,7 @@ private:
                     const size_t i = next.fetch_add(16);
                     if (i >= ms.size()) return;
                     for (size_t j = i; j < std::min(i + 16, ms.size()); j++)
-                        if (!inflate_member(cbuf.data(), ms[j], dst + ms[j].o_off, inf)) {
+                        if (!inflate_member(CD(), ms[j], dst + ms[j].o_off, inf)) {
                             size_t cur = first_bad.load();
                             while (j < cur && !first_bad.compare_exchange_weak(cur, j)) {}
                         }
@@ -524,8 +539,9 @@ private:
         }
         if (n == 0 && foreign && !bad) {                      // the rest is ordinary gzip: continue from that member
             std::string err;
-            const uint64_t at = file_pos - (uint64_t)(cbuf.size() - scan);
+            const uint64_t at = file_pos - (uint64_t)(CN() - scan);
             cbuf.clear(); cpos = 0;
+            if (bmap) { munmap(const_cast<uint8_t *>(bmap), bmap_len); bmap = nullptr; bmap_len = 0; }
             if (open_gzip(at, err) != 0) { bad = true; return 0; }
             return zmap ? read_gzip_mm(dst, cap) : read_gzip(dst, cap);
         }

@@ -57,15 +57,23 @@ def test_gzip_single_and_multi_member(tmp_path, payload, piece):
     assert read_file(z2, piece) == (payload, False, "gzip")
 
 
+@pytest.fixture(params=["mapped", "pread"])
+def bgzf_io(request, monkeypatch):
+    """BGZF files are memory-mapped (the workers fault their own pages in); F2Q_NO_MMAP=1 keeps the buffered pread path"""
+    if request.param == "pread":
+        monkeypatch.setenv("F2Q_NO_MMAP", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("piece", [4096, 1 << 16, 300_000, 1 << 22])
 @pytest.mark.parametrize("threads", [1, 3, 8])
-def test_bgzf(tmp_path, payload, piece, threads):
+def test_bgzf(tmp_path, payload, piece, threads, bgzf_io):
     b = tmp_path / "a.fastq.gz"; b.write_bytes(bgzf_bytes(payload))
     assert gzip.open(b).read() == payload                      # what the reference would see
     assert read_file(b, piece, threads) == (payload, False, "bgzf")
 
 
-def test_bgzf_variants(tmp_path, payload):
+def test_bgzf_variants(tmp_path, payload, bgzf_io):
     for k, kw in enumerate([dict(block=1000), dict(block=65280, level=1), dict(eof_marker=False), dict(extra_subfield=True, block=5000),
                             dict(block=17, level=0)]):
         data = payload if kw.get("block", 0) != 17 else payload[:20000]
@@ -74,7 +82,7 @@ def test_bgzf_variants(tmp_path, payload):
         assert read_file(b, 1 << 16, 4) == (data, False, "bgzf"), kw
 
 
-def test_bgzf_empty_members_inside(tmp_path, payload):
+def test_bgzf_empty_members_inside(tmp_path, payload, bgzf_io):
     raw = bgzf_bytes(payload[:5000], eof_marker=True) + bgzf_bytes(payload[5000:9000], eof_marker=True) + bgzf_bytes(payload[9000:])
     b = tmp_path / "m.gz"; b.write_bytes(raw)
     assert gzip.open(b).read() == payload
@@ -82,7 +90,7 @@ def test_bgzf_empty_members_inside(tmp_path, payload):
 
 
 @pytest.mark.parametrize("cut", [10, 30, 1000, 70_000, -9, -1])
-def test_bgzf_cut_off(tmp_path, payload, cut):
+def test_bgzf_cut_off(tmp_path, payload, cut, bgzf_io):
     raw = bgzf_bytes(payload, eof_marker=False)
     raw = raw[:cut]
     b = tmp_path / "t.gz"; b.write_bytes(raw)
@@ -97,7 +105,7 @@ def test_bgzf_cut_off(tmp_path, payload, cut):
     assert len(got) == whole
 
 
-def test_bgzf_corrupt_member(tmp_path, payload):
+def test_bgzf_corrupt_member(tmp_path, payload, bgzf_io):
     raw = bytearray(bgzf_bytes(payload, block=4000))
     raw[len(raw) // 2] ^= 0x55
     b = tmp_path / "c.gz"; b.write_bytes(bytes(raw))
@@ -105,7 +113,7 @@ def test_bgzf_corrupt_member(tmp_path, payload):
     assert tr and kind == "bgzf" and payload.startswith(got) and len(got) < len(payload)
 
 
-def test_bgzf_then_ordinary_gzip(tmp_path, payload):
+def test_bgzf_then_ordinary_gzip(tmp_path, payload, bgzf_io):
     a, c = payload[:100_000], payload[100_000:]
     b = tmp_path / "mix.gz"; b.write_bytes(bgzf_bytes(a, eof_marker=False) + gzip.compress(c))
     assert gzip.open(b).read() == payload
