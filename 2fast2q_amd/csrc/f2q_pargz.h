@@ -297,6 +297,7 @@ struct ParGunzip {
     size_t chunk_bytes = (size_t)2 << 20;                  // compressed bytes per chunk (F2Q_GZ_CHUNK_KB)
     uint64_t rounds = 0, chunks_ok = 0, chunks_dropped = 0;   // diagnostics
     double ratio = 6.0;                                    // text bytes per compressed byte in the last round (first guess: FASTQ)
+    double lead_ratio = 0.0;                               // extra input (in chunks) the first chunk of a round takes, see round()
     Inflater first;                                        // the first chunk of a round: known window, plain decoder
     std::vector<SpecInflater *> spec;
     std::vector<RawBuf<uint16_t> *> sym, scratch;
@@ -332,7 +333,7 @@ struct ParGunzip {
             if (room == 0) { *produced = 0; return Inflater::OUT_FULL; }
             // a round's text goes straight into dst when it fits; when the caller's piece is partly filled and the next
             // round is not expected to fit, the piece ends here (a short read) instead of being topped up through `stage`
-            if (n > 0 && (double)(room - n) < ratio * 1.15 * (double)chunk_bytes * (double)n_threads) { *produced = n; return Inflater::OUT_FULL; }
+            if (n > 0 && (double)(room - n) < ratio * 1.15 * (double)chunk_bytes * ((double)n_threads + lead_ratio)) { *produced = n; return Inflater::OUT_FULL; }
             n += round(dst + n, room - n);
         }
     }
@@ -368,29 +369,37 @@ private:
         std::vector<Chunk> ch((size_t)T);
         ch[0].start = pos_bit;
         const uint64_t first_byte = pos_bit >> 3;
+        // chunk 0 knows its window and runs the plain decoder, 2.2x as fast as the speculative one and without a search:
+        // it takes 2.2 chunks' worth of input so that the workers finish together
+        // (lead_ratio: how much faster it was than the speculative decoders in the rounds so far, measured -- 1.2 on the
+        //  GPU box's host, 0 .. 0.5 on slower machines)
+        const uint64_t lead = T > 1 ? (uint64_t)((double)chunk_bytes * lead_ratio) : 0;
         // ---- 1 + 2. every worker finds where its chunk starts, then decodes it up to the start behind it ------------
         std::vector<uint64_t> stop((size_t)T, ~0ull);
         std::atomic<int> found{1};                              // starts known so far (chunk 0's is)
         const size_t sym_limit = std::max<size_t>((size_t)64 << 20, chunk_bytes * 64);
         double t_1 = t_0;
+        std::vector<double> spent((size_t)T, 0.0);
         auto work = [&](int i) {
             Chunk &c = ch[(size_t)i];
+            const double w_0 = now_s();
+            struct Stamp { double &d, t0; ~Stamp() { d = now_s() - t0; } } stamp{spent[(size_t)i], w_0};
             if (i > 0) {
-                const uint64_t from = (first_byte + (uint64_t)i * chunk_bytes) * 8, to = from + (uint64_t)chunk_bytes * 8;
+                const uint64_t from = (first_byte + lead + (uint64_t)i * chunk_bytes) * 8, to = from + (uint64_t)chunk_bytes * 8;
                 if (from < total_bits) c.start = find_block_start(base, len, from, std::min(to, total_bits), *spec[(size_t)i], *scratch[(size_t)i]);
                 found.fetch_add(1, std::memory_order_release);
             }
             while (found.load(std::memory_order_acquire) < T) std::this_thread::yield();     // (a few milliseconds at most)
-            if (i == 0) t_1 = now_s();
+            if (i == 0) { t_1 = now_s(); stamp.t0 = t_1; }            // (chunk 0 has only waited so far)
             // this chunk runs to the next start that was found; the last one to the first boundary behind the round's stretch
-            uint64_t stop_at = (first_byte + (uint64_t)T * chunk_bytes) * 8;
+            uint64_t stop_at = (first_byte + lead + (uint64_t)T * chunk_bytes) * 8;
             for (int j = T - 1; j > i; j--) if (ch[(size_t)j].start != ~0ull) stop_at = ch[(size_t)j].start;
             stop[(size_t)i] = stop_at;
             if (c.start == ~0ull) return;
             if (i == 0) {
                 if (!first.reset_at(base, len, c.start, window.data(), (uint32_t)window.size())) { c.rc = Inflater::ERR; return; }
                 first.stop_bit = stop_at;
-                text0.reserve(std::max<size_t>(chunk_bytes * 5, (size_t)1 << 20));
+                text0.reserve(std::max<size_t>((size_t)((double)chunk_bytes * ratio * 1.25 * (1.0 + lead_ratio)), (size_t)1 << 20));
                 size_t o = 0;
                 for (;;) {
                     size_t got = 0;
@@ -417,6 +426,17 @@ private:
             for (auto &x : th) x.join();
         }
         const double t_2 = now_s();
+        if (T > 1 && ch[0].end > ch[0].start && spent[0] > 0) {
+            // bytes of input per second: the plain decoder of chunk 0 against the mean of the speculative ones (search included)
+            double rs = 0; int ns = 0;
+            for (int i = 1; i < T; i++)
+                if (ch[(size_t)i].start != ~0ull && ch[(size_t)i].end > ch[(size_t)i].start && spent[(size_t)i] > 0 && ch[(size_t)i].rc != Inflater::ERR) { rs += (double)(ch[(size_t)i].end - ch[(size_t)i].start) / spent[(size_t)i]; ns++; }
+            if (ns) {
+                const double r0 = (double)(ch[0].end - ch[0].start) / spent[0];
+                const double want = std::min(3.0, std::max(0.0, r0 / (rs / ns) - 1.0));
+                lead_ratio = 0.5 * lead_ratio + 0.5 * want;
+            }
+        }
         // ---- 3. the chain: which chunks stand ----------------------------------------------------------------
         int last = 0;                                          // index of the last chunk whose text is kept
         bool ended = ch[0].rc != Inflater::BOUNDARY;
