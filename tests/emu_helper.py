@@ -16,7 +16,7 @@ binding = importlib.import_module("2fast2q_amd.binding")
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("f2q_device.h", "f2q_host.h", "f2q_synth.h", "f2q_reader.h", "f2q_inflate.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("f2q_device.h", "f2q_host.h", "f2q_synth.h", "f2q_reader.h", "f2q_inflate.h", "f2q_pargz.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                                "-o", LIB, SRC, "-lz", "-lpthread"])
