@@ -367,7 +367,7 @@ def main(argv=None, engine=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     name, scaling, w = resolve(a, world)
-    dominant = "k_extract_fixed4" if w.get("ec") and not w.get("anchored") else "k_count_anchor_pairs" if w.get("pairs") else "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4" if w.get("windows") else "k_count_fixed4|k_part_"
+    dominant = "k_extract_fixed4" if w.get("ec") and not w.get("anchored") else "k_count_anchor_pairs" if w.get("pairs") else "k_extract_anchor" if w.get("anchored") and w.get("ec") else "k_count_anchor" if w.get("anchored") else "k_count_multi4|k_count_fixed4_lds" if w.get("windows") else "k_count_fixed4|k_part_"
     # (a fixed window is counted by k_count_fixed4[_lds] or, large libraries, by the k_part_scatter / k_part_count / k_part_reduce
     # sequence: the PMC passes sum whichever family the step launched; `roofline.kernel` names the one that ran, from f2q_timing.path)
 
@@ -430,7 +430,8 @@ def main(argv=None, engine=None):
 
     dt, k_ms, path = timed_steps(c, blk, a.steps, a.warmup, allreduce, barrier, sync)
     if "|" in dominant:
-        dominant = {4: "k_part_scatter + k_part_count + k_part_reduce", 3: "k_count_fixed4_lds", 2: "k_count_fixed4"}.get(path, "k_count_fixed4")
+        dominant = {4: "k_part_scatter + k_part_count + k_part_reduce", 3: "k_count_fixed4_lds", 2: "k_count_fixed4", 5: "k_count_multi4",
+                    10: "k_count_fixed4_lds<.., MW> (windows back to back on the tiles)"}.get(path, dominant.split("|")[0])
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
