@@ -149,6 +149,16 @@ struct GkDesc { uint32_t n_groups, pad; const GkGroup *grp; const uint32_t *tab;
 // multi-window runs (--st a,b,...): a key is the ':'-joined windows that passed their Phred test (fast2q.py:349-363);
 // features made of k ACGT runs of --l bases joined by ':' ("k-part features") are indexed by their k*l bases
 #define F2Q_MW_MAX 4               // windows of a run the packed path handles (k * l <= 31 bases)
+// "Pair tables": runs with two --us/--ds pairs (k_count_anchor_pairs) against a library whose features ALL read A:B with
+// A of la and B of lb ACGT bases (la, lb <= 20) -- dual-guide libraries, also combinatorial ones.  The joined key is held
+// as two 2-bit words instead of a string; three open-addressing tables of 16-byte slots {A | feature << 40, B}: one hashed
+// by (A, B) for the exact hit, one by A and one by B for --m 1 (a feature at distance 1 from the key agrees with it on
+// exactly one of the two parts; the features sharing that part sit along its probe sequence).  Empty slot: B = ~0.
+struct PwDesc {
+    uint32_t ok, la, lb, bits;         // every table has 1 << bits slots
+    const uint64_t *tab;               // [3][1 << bits][2]
+};
+
 struct LibDev {
     uint32_t n_features, n_irregular;
     const uint64_t *ptab;              // packed slots (KEY_EMPTY = free)
@@ -158,6 +168,7 @@ struct LibDev {
     LtDesc lt;
     PtDesc pt;
     GkDesc gk;
+    PwDesc pw;
     const uint64_t *tab_keys;          // open-addressing slots: 2-bit feature key or KEY_EMPTY
     const uint32_t *tab_idx;           // feature index of the slot
     const uint8_t *feat_bytes;         // all features, raw (upper-case) bytes
@@ -1854,12 +1865,88 @@ F2Q_HD AnchorWin anchor_window(const RunDev &run, const uint32_t (&LO)[NW], cons
 // kb: F2Q_PAIRS_KEYMAX bytes of the lane's own (the kernel hands out LDS, 68-byte stride: an odd number of words; two
 // parts of 31 bases and their ':' fit, a longer key takes the byte-exact routine)
 #define F2Q_PAIRS_KEYMAX 68
+// 2-bit interleaved key of window [start, start+L) (L <= 31) from the planes
+template <int NW>
+F2Q_HD uint64_t plane_key(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], int start, int L)
+{
+    return spread32(plane_extract<NW>(LO, start, L)) | (spread32(plane_extract<NW>(HI, start, L)) << 1);
+}
+
+// ---- pair tables (PwDesc): the joined key of a two-pair run as two 2-bit words --------------------------------------
+#define F2Q_PW_MAXLEN 20
+#define F2Q_PW_AMASK ((1ull << 40) - 1ull)
+F2Q_HD uint32_t pw_hash(uint64_t a, uint64_t b, uint32_t bits) { return hash32(a * 0x9E3779B97F4A7C15ull + (b ^ (b >> 17)) * 0xC2B2AE3D27D4EB4Full, bits); }
+// The Counter-mode verdict for the key A:B (fa / fb: one bit per base of A / B that is no ACGT symbol -- a forced
+// mismatch): exact hit (fast2q.py:365-367), else with --m 1 the unique feature at distance 1 (:692-750).  idx = feature.
+F2Q_HD int pw_decide(const PwDesc &pw, uint64_t a, uint64_t b, uint32_t fa, uint32_t fb, int miss, uint32_t &idx)
+{
+    const uint32_t mask = (1u << pw.bits) - 1u;
+    const uint64_t *t0 = pw.tab, *t1 = pw.tab + ((size_t)2 << pw.bits), *t2 = pw.tab + ((size_t)4 << pw.bits);
+    if (!(fa | fb)) {
+        for (uint32_t s = pw_hash(a, b, pw.bits);; s = (s + 1u) & mask) {
+            const uint64_t w0 = gp(t0)[2u * s], w1 = gp(t0)[2u * s + 1u];
+            if (w1 == ~0ull) break;
+            if ((w0 & F2Q_PW_AMASK) == a && w1 == b) { idx = (uint32_t)(w0 >> 40); return 1; }
+        }
+    }
+    if (miss < 1) return 3;
+    const int nf = popc64(fa) + popc64(fb);
+    if (nf > 1) return 3;
+    uint32_t cnt = 0;
+    if (!fa) {                                   // the features with this A: is their B one base (the flagged one) away?
+        const uint64_t keep = ~(spread32(fb) * 3ull);
+        for (uint32_t s = pw_hash(a, 0ull, pw.bits);; s = (s + 1u) & mask) {
+            const uint64_t w0 = gp(t1)[2u * s], w1 = gp(t1)[2u * s + 1u];
+            if (w1 == ~0ull) break;
+            if ((w0 & F2Q_PW_AMASK) == a && ham2((w1 ^ b) & keep) + nf == 1) { cnt++; idx = (uint32_t)(w0 >> 40); }
+        }
+    }
+    if (!fb) {                                   // ... and those with this B
+        const uint64_t keep = ~(spread32(fa) * 3ull);
+        for (uint32_t s = pw_hash(b, 1ull, pw.bits);; s = (s + 1u) & mask) {
+            const uint64_t w0 = gp(t2)[2u * s], w1 = gp(t2)[2u * s + 1u];
+            if (w1 == ~0ull) break;
+            if (w1 == b && ham2(((w0 & F2Q_PW_AMASK) ^ a) & keep) + nf == 1) { cnt++; idx = (uint32_t)(w0 >> 40); }
+        }
+    }
+    return cnt == 1u ? 2 : 3;
+}
+
 template <int NW, int KB>
 F2Q_HD int pairs_lane(const RunDev &run, const LibDev &lib, const EcDev &ec, uint8_t *kb,
                       const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], const uint32_t (&FLG)[NW], int r,
                       const uint32_t (&FU)[NW], const uint32_t (&FD)[NW], const uint32_t (&FW)[NW],
                       unsigned long long read_index, uint32_t &idx, uint32_t *n_new, bool keyflag = true)
 {   // keyflag = false: the marks of FLG are lower-case bases (F2Q_LEN_CASE): mismatches for the anchors, plain bases in the key
+    if (run.mode == 0 && lib.pw.ok && run.n_iter == 2) {
+        // two pairs against a library of A:B features: the joined key as two 2-bit words (PwDesc), no string
+        const PwDesc &pw = lib.pw;
+        uint64_t key[2] = {0, 0}; uint32_t fl[2] = {0, 0}; int len[2] = {0, 0}, np = 0;
+        for (int i = 0; i < 2; i++) {
+            const AnchorWin aw = anchor_window_pair<NW, KB, KB>(run, run.up_len[i], run.down_len[i], run.mp_up_pos[i], run.mp_down_pos[i],
+                                                                LO, HI, FLG, r, FU, FD, FW);
+            if (aw.ok == 2) return -1;
+            if (aw.ok != 1) continue;
+            const int L = aw.end - aw.start;
+            if (L > F2Q_REG_MAXLEN) return -1;                            // (no 2-bit form: the byte-exact routine)
+            key[np] = plane_key<NW>(LO, HI, aw.start, L);
+            fl[np] = keyflag ? plane_extract<NW>(FLG, aw.start, L) : 0u;
+            len[np] = L; np++;
+        }
+        if (!np) return 4;                                                // :389-390
+        if (np == 2) {
+            // parts of other lengths: the ':' of the key and of every feature sit at different places, two mismatches at least
+            if (len[0] != (int)pw.la || len[1] != (int)pw.lb) return 3;
+            return pw_decide(pw, key[0], key[1], fl[0], fl[1], run.miss, idx);
+        }
+        // one part (the other pair was not found): a plain key.  As long as A:B it can be one substitution away from a
+        // feature -- the base where the feature has its ':' -- when everything else agrees
+        if (len[0] == (int)(pw.la + 1u + pw.lb) && run.miss >= 1 && (fl[0] & ~(1u << pw.la)) == 0u) {
+            const uint64_t a = key[0] & ((1ull << (2u * pw.la)) - 1ull), b = key[0] >> (2u * (pw.la + 1u));
+            return pw_decide(pw, a, b, 0u, 0u, 0, idx) == 1 ? 2 : 3;
+        }
+        return 3;
+    }
     int klen = 0, nparts = 0;
     for (int i = 0; i < run.n_iter; i++) {
         const AnchorWin aw = anchor_window_pair<NW, KB, KB>(run, run.up_len[i], run.down_len[i], run.mp_up_pos[i], run.mp_down_pos[i],
@@ -1885,12 +1972,6 @@ F2Q_HD int pairs_lane(const RunDev &run, const LibDev &lib, const EcDev &ec, uin
     return 0;
 }
 
-// 2-bit interleaved key of window [start, start+L) (L <= 31) from the planes
-template <int NW>
-F2Q_HD uint64_t plane_key(const uint32_t (&LO)[NW], const uint32_t (&HI)[NW], int start, int L)
-{
-    return spread32(plane_extract<NW>(LO, start, L)) | (spread32(plane_extract<NW>(HI, start, L)) << 1);
-}
 
 // ---------------------------------------------------------------------------------------------
 // packing: which reads the tile planes can carry, and how one read is laid into them.  Shared by the

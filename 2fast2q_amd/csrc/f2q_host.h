@@ -42,6 +42,9 @@ struct HostIndex {
     std::vector<unsigned long long> gk_fw;
     LenGroup grp[F2Q_REG_MAXLEN + 1];
     uint32_t n_features = 0, n_irregular = 0;
+    // pair tables (f2q_device.h: PwDesc); pw.ok == 0: the library is not a pure A:B library
+    PwDesc pw{};
+    std::vector<uint64_t> pw_tab;
 };
 
 inline bool feature_key(const uint8_t *s, uint32_t n, uint64_t &key)
@@ -264,6 +267,44 @@ inline void build_pt(HostIndex &ix, const std::vector<uint32_t> &ids, int len, i
     }
 }
 
+// Pair tables (f2q_device.h: PwDesc): every feature reads A:B, all A of one length and all B of one length (<= 20 ACGT
+// bases each), --m <= 1.  Built for every such library; only two-pair anchored runs in Counter mode ask them.
+inline void build_pw(HostIndex &ix, int miss)
+{
+    memset(&ix.pw, 0, sizeof ix.pw);
+    ix.pw_tab.assign(2, ~0ull);
+    const uint32_t n = ix.n_features;
+    if (n == 0 || miss > 1 || n >= (1u << 24)) return;
+    std::vector<uint64_t> ka(n), kb(n);
+    uint32_t la = 0, lb = 0;
+    for (uint32_t f = 0; f < n; f++) {
+        const uint8_t *s = ix.feat_bytes.data() + ix.feat_off[f];
+        const uint32_t len = ix.feat_off[f + 1] - ix.feat_off[f];
+        const uint8_t *c = (const uint8_t *)memchr(s, ':', len);
+        if (!c) return;
+        const uint32_t a = (uint32_t)(c - s), b = len - a - 1u;
+        if (f == 0) { la = a; lb = b; }
+        if (a != la || b != lb || a < 1 || b < 1 || a > F2Q_PW_MAXLEN || b > F2Q_PW_MAXLEN) return;
+        if (!feature_key(s, a, ka[f]) || !feature_key(c + 1, b, kb[f])) return;       // (a second ':' or any other symbol)
+    }
+    uint32_t bits = 4;
+    while ((1ull << bits) < 4ull * n) bits++;
+    const uint32_t mask = (1u << bits) - 1u;
+    ix.pw_tab.assign((size_t)6 << bits, ~0ull);
+    auto put = [&](int t, uint32_t s0, uint32_t f) {
+        uint64_t *tab = ix.pw_tab.data() + ((size_t)(2 * t) << bits);
+        uint32_t s = s0;
+        while (tab[2u * s + 1u] != ~0ull) s = (s + 1u) & mask;
+        tab[2u * s] = ka[f] | ((uint64_t)f << 40); tab[2u * s + 1u] = kb[f];
+    };
+    for (uint32_t f = 0; f < n; f++) {
+        put(0, pw_hash(ka[f], kb[f], bits), f);
+        put(1, pw_hash(ka[f], 0ull, bits), f);
+        put(2, pw_hash(kb[f], 1ull, bits), f);
+    }
+    ix.pw.ok = 1; ix.pw.la = la; ix.pw.lb = lb; ix.pw.bits = bits;
+}
+
 // byte-string index of ALL features, by length (f2q_device.h: GkDesc): exact table + m+1 pigeonhole piece tables per group
 inline void build_gk(HostIndex &ix, int miss)
 {
@@ -422,6 +463,7 @@ inline void build_index(HostIndex &ix, const char *seqs, const uint32_t *offs, u
     }
     build_pt(ix, (packed_len >= 1 && packed_len <= F2Q_REG_MAXLEN) ? by_len[packed_len] : std::vector<uint32_t>(), packed_len, miss, ix.pt_force_parts);
     build_gk(ix, miss);
+    build_pw(ix, miss);
     ix.n_irregular = (uint32_t)ix.irr_ids.size();
     if (ix.irr_ids.empty()) ix.irr_ids.push_back(0);     // keep the device array non-empty
 }

@@ -253,6 +253,10 @@ static int upload_lib(f2q_ctx *c)
         if ((rc = dev_upload(c, c->ix.lt_feat_of.data(), c->ix.lt_feat_of.size(), &lt_feat, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.lt_slot_of.data(), c->ix.lt_slot_of.size(), &lt_slot, c->lib_allocs))) return rc;
         L.lt = c->ix.lt; L.lt.tags = lt_tags; L.lt.feat_of = lt_feat; L.lt.slot_of = lt_slot;
+        uint64_t *pw_tab;
+        if ((rc = dev_upload(c, c->ix.pw_tab.data(), c->ix.pw_tab.size(), &pw_tab, c->lib_allocs))) return rc;
+        L.pw = c->ix.pw; L.pw.tab = pw_tab;
+        { const char *e = getenv("F2Q_NO_PW"); if (e && e[0] == '1') L.pw.ok = 0; }      // A/B runs: the joined key as a string (byte-string index)
         uint32_t *pt_t0, *pt_t1, *pt_ps, *pt_s1, *pt_fo, *pt_f0; uint16_t *pt_s0;
         if ((rc = dev_upload(c, c->ix.pt_tags0.data(), c->ix.pt_tags0.size(), &pt_t0, c->lib_allocs))) return rc;
         if ((rc = dev_upload(c, c->ix.pt_tags1.data(), c->ix.pt_tags1.size(), &pt_t1, c->lib_allocs))) return rc;
@@ -411,6 +415,9 @@ extern "C" int f2q_set_features(f2q_ctx *c, const char *seqs, const uint32_t *of
     rc = alloc_acc(c, n);
     if (rc) return rc;
     c->plan.inband_n = (c->plan.fast_fixed || c->plan.fast_anchor) && c->ix.n_irregular == 0;
+    // two pairs against a pure A:B library (pair tables): an 'N' travels as a flag bit (a forced mismatch; it equals no
+    // symbol of any feature), every other odd symbol still sends the read to the byte-exact routine
+    if (c->plan.fast_anchor && c->plan.multi_pair && c->prm.mode == 0 && c->run_h.n_iter == 2 && c->lib_h.pw.ok) { c->plan.inband_n = true; c->plan.n_only = true; }
     if (c->ix.n_irregular && !c->plan.multi_pair) c->plan.fast_anchor = false;      // irregular features need the byte-exact routine (the pair kernel matches strings)
     c->have_lib = true;
     return F2Q_OK;

@@ -23,7 +23,7 @@ struct Emu {
     std::vector<unsigned long long> acc;      // counts + 5 stats
     EcDev ec; std::vector<unsigned long long> slots, ent_off, ent_count, ent_first, ctr, k64s, k64c, k64f; std::vector<uint32_t> ent_len, arena;
     uint64_t reads_seen = 0, fast = 0, general = 0, v2_reads = 0, anchor_reads = 0;
-    int use_v2 = 1, use_lt = 1;
+    int use_v2 = 1, use_lt = 1, use_pw = 1;
     uint64_t lt_reads = 0, pt_reads = 0;
     std::string err;
 };
@@ -37,6 +37,7 @@ static void bind_lib(Emu *e)
     memcpy(L.mpk, e->ix.mpk, sizeof L.mpk); L.mw_ok = e->ix.mw_ok;
     L.feat_bytes = e->ix.feat_bytes.data(); L.feat_off = e->ix.feat_off.data(); L.irr_ids = e->ix.irr_ids.data();
     L.lt = e->ix.lt; L.lt.tags = e->ix.lt_tags.data(); L.lt.slot_of = e->ix.lt_slot_of.data();
+    L.pw = e->ix.pw; L.pw.tab = e->ix.pw_tab.data(); if (!e->use_pw) L.pw.ok = 0;
     L.lt.feat_of = e->ix.lt_feat_of.data();
     L.pt = e->ix.pt; L.pt.tags0 = e->ix.pt_tags0.data(); L.pt.tags1 = e->ix.pt_tags1.data(); L.pt.pstart = e->ix.pt_pstart.data();
     L.pt.slot0_of = e->ix.pt_slot0_of.data(); L.pt.slot1_of = e->ix.pt_slot1_of.data(); L.pt.feat_of = e->ix.pt_feat_of.data();
@@ -86,6 +87,7 @@ void emu_set_features(void *h, const char *seqs, const uint32_t *offs, uint32_t 
     if (e->plan.multi && (!e->ix.mw_ok || e->ix.n_irregular)) { e->plan.multi = false; e->plan.fast_fixed = false; }
     bind_lib(e);
     e->plan.inband_n = (e->plan.fast_fixed || e->plan.fast_anchor) && e->ix.n_irregular == 0;
+    if (e->plan.fast_anchor && e->plan.multi_pair && e->run.mode == 0 && e->run.n_iter == 2 && e->lib.pw.ok) { e->plan.inband_n = true; e->plan.n_only = true; }
     if (e->ix.n_irregular && !e->plan.multi_pair) e->plan.fast_anchor = false;
 }
 
@@ -515,6 +517,8 @@ void emu_set_read_base(void *h, uint64_t b) { ((Emu *)h)->reads_seen = b; }
 void emu_reset(void *h) { Emu *e = (Emu *)h; std::fill(e->acc.begin(), e->acc.end(), 0ull); e->reads_seen = 0; e->fast = 0; e->general = 0; }   // f2q_reset_counts (Counter mode)
 void emu_use_v2(void *h, int on) { ((Emu *)h)->use_v2 = on; }
 void emu_use_lt(void *h, int on) { ((Emu *)h)->use_lt = on; }
+void emu_use_pw(void *h, int on) { ((Emu *)h)->use_pw = on; }      // before emu_set_features
+int emu_pw_ok(void *h) { return (int)((Emu *)h)->lib.pw.ok; }
 uint64_t emu_lt_reads(void *h) { return ((Emu *)h)->lt_reads; }
 int emu_lt_ok(void *h) { return (int)((Emu *)h)->ix.lt.ok; }
 void emu_pt_force(void *h, int parts) { ((Emu *)h)->ix.pt_force_parts = parts; }      // before emu_set_features

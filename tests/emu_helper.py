@@ -45,6 +45,8 @@ def lib():
         L.emu_v2_reads.restype = C.c_uint64
         L.emu_v2_reads.argtypes = [vp]
         L.emu_use_lt.argtypes = [vp, C.c_int]
+        L.emu_use_pw.argtypes = [vp, C.c_int]
+        L.emu_pw_ok.argtypes = [vp]
         L.emu_lt_reads.restype = C.c_uint64
         L.emu_lt_reads.argtypes = [vp]
         L.emu_lt_ok.argtypes = [vp]
@@ -82,13 +84,14 @@ def read_file(path, piece=1 << 16, threads=0, out_cap=1 << 26):
 
 
 class Emu:
-    def __init__(self, features=None, v2=True, lt=True, pt_parts=0, **params):
+    def __init__(self, features=None, v2=True, lt=True, pt_parts=0, pw=True, **params):
         self._p, self._keep = binding.make_params(**params)
         self._h = C.c_void_p(lib().emu_create(C.byref(self._p)))
         if not self._h:
             raise ValueError("emu_create failed")
         lib().emu_use_v2(self._h, 1 if v2 else 0)
         lib().emu_use_lt(self._h, 1 if lt else 0)
+        lib().emu_use_pw(self._h, 1 if pw else 0)      # pair tables (two-pair runs, A:B libraries); False: the string index
         if pt_parts:
             lib().emu_pt_force(self._h, pt_parts)      # partitioned tables whatever the library's size (F2Q_PT_PARTS)
         self.n = 0
@@ -124,6 +127,9 @@ class Emu:
 
     def lt_ok(self):
         """the cuckoo build of the LDS tables succeeded for the library"""
+
+    def pw_ok(self):
+        return bool(lib().emu_pw_ok(self._h))
         return bool(lib().emu_lt_ok(self._h))
 
     def anchor_reads(self):

@@ -725,6 +725,29 @@ def test_multi_pair_packed_kernel_vs_oracle(P, monkeypatch, mode, ms, three):
     assert res[0][1] == (o.counts() if mode == "C" else list(zip(o.keys(), o.counts())))
 
 
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("la,lb,combinatorial,ms", [(18, 18, False, 1), (20, 20, True, 0), (10, 12, False, 1), (7, 20, True, 1), (14, 9, False, 2)])
+def test_pair_tables_kernel_vs_oracle(P, monkeypatch, miss, la, lb, combinatorial, ms):
+    """k_count_anchor_pairs with the pair tables (two --us/--ds pairs, a pure A:B library: the joined key as two 2-bit words)
+    against the oracle, the string index (F2Q_NO_PW=1) and the byte-exact general kernel"""
+    from test_lane_logic_cpu import pair_library_case, UP, UP2, DOWN, DOWN2
+    lib, fq = pair_library_case(30000, 3 * la + lb + ms + 1, la, lb, combinatorial)
+    kw = dict(miss=miss, upstream=f"{UP},{UP2}", downstream=f"{DOWN},{DOWN2}", miss_search_up=ms, miss_search_down=ms)
+    o = O.count_fastq_parallel(fq, 8, features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    res = []
+    for env in ({}, {"F2Q_NO_PW": "1"}, {"F2Q_FORCE_GENERAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with P.Counter(features=lib, **kw) as c:
+            _, t = c.count_block(fq, want_timing=True)
+            counts, stats = c.read_counts()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert list(stats) == o.stats() and list(counts) == o.counts(), env
+        res.append((t["path"], t["general_reads"], t["kernel_ms"]))
+    assert res[0][0] == 8 and res[1][0] == 8 and res[0][1] < 3000 and res[2][1] == 30000        # F2Q_PATH_PAIRS
+
+
 def test_two_window_full_size(P, monkeypatch):
     """50M reads, two 10-base windows (--st 0,10 --l 10) against 10k two-part features: the packed multi-window kernel
     against the single-window run of the 20-base form of the same library on the same reads (same counts: see below),

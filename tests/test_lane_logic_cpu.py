@@ -399,6 +399,65 @@ def test_multi_pair_packed_logic_vs_oracle(mode, ms, three):
         assert any(":" in k for k in o.keys())
 
 
+def pair_library_case(n_reads, seed, la=18, lb=18, combinatorial=False, n_feat=150):
+    """two cassettes UP + A + DOWN, UP2 + B + DOWN2 against a library of A:B features only (dual-guide libraries): pairs of
+    unrelated guides, or combinatorial (a guide with several partners); substitutions, N, low qualities, destroyed
+    cassettes, windows of other lengths, a lone cassette whose window is as long as a joined key"""
+    import random
+    rng = random.Random(seed)
+    ga, gb = synth.make_library(n_feat, la, 400 + seed), synth.make_library(n_feat, lb, 500 + seed)
+    if combinatorial:
+        lib = list(dict.fromkeys(f"{ga[i % 12]}:{gb[(i * 7) % 40]}" for i in range(3 * n_feat)))
+    else:
+        lib = [f"{ga[i]}:{gb[i]}" for i in range(n_feat)]
+    recs = []
+    for i in range(n_reads):
+        a, b = rng.choice(lib).split(":")
+        if rng.random() < 0.1:
+            b = rng.choice(gb)                                        # a pair the library may not hold
+        if rng.random() < 0.04:
+            a = a[:-1] if rng.random() < 0.5 else a + rng.choice("ACGT")      # a window of another length
+        seq = "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 9)))
+        if rng.random() < 0.03 and la + 1 + lb <= 31:
+            seq += UP + a + rng.choice("ACGTN") + b + DOWN             # one cassette around A?B: one substitution from A:B
+        else:
+            seq += UP + a + DOWN + "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 6))) + UP2 + b + DOWN2
+        seq += "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 6)))
+        bts = bytearray(seq.encode())
+        q = bytearray(b"I" * len(bts))
+        for _ in range(rng.choice([0, 0, 0, 1, 1, 2, 3])):
+            bts[rng.randrange(len(bts))] = rng.choice(b"ACGT")
+        if rng.random() < 0.06:
+            bts[rng.randrange(len(bts))] = ord("N")
+        if rng.random() < 0.2:
+            q[rng.randrange(len(q))] = rng.choice(b"#+5:")
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, bytes(bts), bytes(q)))
+    return lib, b"".join(recs)
+
+
+@pytest.mark.parametrize("miss", [0, 1])
+@pytest.mark.parametrize("la,lb,combinatorial,ms", [(18, 18, False, 1), (20, 20, True, 0), (10, 12, False, 1), (7, 20, True, 1), (14, 9, False, 2)])
+def test_pair_tables_vs_oracle(miss, la, lb, combinatorial, ms):
+    """two --us/--ds pairs against a pure A:B library: the joined key as two 2-bit words through the pair tables (PwDesc:
+    exact by (A, B), --m 1 through the features sharing A or sharing B) -- against the oracle and the string index"""
+    lib, fq = pair_library_case(4000, 3 * la + lb + ms, la, lb, combinatorial)
+    kw = dict(miss=miss, upstream=f"{UP},{UP2}", downstream=f"{DOWN},{DOWN2}", miss_search_up=ms, miss_search_down=ms)
+    o = O.Oracle(features=[(str(i), s) for i, s in enumerate(lib)], **kw)
+    o.count_fastq(fq)
+    e = Emu(features=lib, **kw)
+    assert e.pw_ok()
+    e.count_block(fq)
+    counts, stats, fast, gen = e.read()
+    assert stats == o.stats() and counts == o.counts()
+    assert fast > 0.9 * stats[0] and stats[1] > 1000 and (miss == 0 or stats[2] > 50)
+    e2 = Emu(features=lib, pw=False, **kw)
+    assert not e2.pw_ok()
+    e2.count_block(fq)
+    assert e2.read()[:2] == (counts, stats)
+    # a library with a feature of another shape keeps to the string index
+    assert not Emu(features=lib + [lib[0].split(":")[0]], **kw).pw_ok() and not Emu(features=lib + [lib[0] + ":" + lib[1]], **kw).pw_ok()
+
+
 @pytest.mark.parametrize("mode", ["C", "EC"])
 @pytest.mark.parametrize("anchors", ["both", "up", "down"])
 @pytest.mark.parametrize("ms,qs", [(0, 30), (1, 30), (2, 30), (1, 12), (3, 41)])
