@@ -127,10 +127,11 @@ class Emu:
 
     def lt_ok(self):
         """the cuckoo build of the LDS tables succeeded for the library"""
+        return bool(lib().emu_lt_ok(self._h))
 
     def pw_ok(self):
+        """pair tables were built (a pure A:B library) and are in use"""
         return bool(lib().emu_pw_ok(self._h))
-        return bool(lib().emu_lt_ok(self._h))
 
     def anchor_reads(self):
         return lib().emu_anchor_reads(self._h)
