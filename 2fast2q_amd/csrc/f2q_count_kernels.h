@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor(const RunDev *_
 // a string (byte-string index, or the 2-bit tables when neither key nor library holds a ':').  Counter mode counts in an
 // LDS histogram when the library fits, Extract+Count inserts in place (the host reserves for every read of the view).
 template <int NW, int KB, bool SAMEQ, bool USE_LDS>
-__global__ __launch_bounds__(F2Q_AN_THREADS) void k_count_anchor_pairs(const RunDev *__restrict__ runp, const LibDev *__restrict__ libp,
+__global__ __launch_bounds__(F2Q_AN_THREADS, 4) void k_count_anchor_pairs(const RunDev *__restrict__ runp, const LibDev *__restrict__ libp,
                                                                        EcDev ec, PackedBlock pb, Accum acc, uint64_t read_base)
 {
     constexpr int NQW = 8 * NW;

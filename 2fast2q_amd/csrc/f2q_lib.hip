@@ -663,7 +663,7 @@ static int launch_view(f2q_ctx *c, const PackedBlock &pb, const RawBlock &rbv, A
         // several --us/--ds pairs on the planes
         c->last_path = F2Q_PATH_PAIRS;
         const bool lds = c->prm.mode == 0 && c->lib_h.n_features <= F2Q_HIST_MAX;
-        const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * 6u);
+        const uint32_t grid = std::min<uint32_t>(pb.n_tiles, (uint32_t)c->n_cu * 8u);          // (four workgroups of 256 threads are resident per CU at 128 VGPRs: two rounds)
         const size_t shmem = lds ? std::max<size_t>(4, (((size_t)c->lib_h.n_features + 1) / 2) * 4) : 4;
         const int nw = (int)pb.planar_nw, kb = c->plan.kb;
         const bool sameq = c->run_h.thr_up == c->run_h.thr && c->run_h.thr_down == c->run_h.thr;
