@@ -20,11 +20,13 @@ counts its share of each file's record blocks and the int64 count vector is summ
 all-reduce (sharding.py).
 """
 import argparse
+import atexit
 import csv
 import datetime
 import glob
 import os
 import sys
+import threading
 import time
 from dataclasses import dataclass
 from pathlib import Path
@@ -106,6 +108,54 @@ def _counter_kwargs(param):
                 device=int(param.get('device', os.environ.get("F2Q_DEVICE", os.environ.get("LOCAL_RANK", 0)))))
 
 
+# ---- contexts are kept between samples ----------------------------------------------------------------------------
+# A run counts many samples against ONE library with ONE set of parameters.  Creating a context per sample would build and
+# upload the library index and allocate (and pin) the staging buffers every time -- 50 ms to several hundred per sample, as
+# much as counting a small sample takes.  Each worker thread keeps its context; it is reset between samples
+# (f2q_reset_counts: accumulators, Extract+Count tables, read numbering) and closed when the run ends.
+_CTX_LOCK = threading.Lock()
+_CTX_ALL = []
+_CTX_TLS = threading.local()
+_CTX_GEN = [0]
+
+
+def _context_for(seqs, kwargs):
+    key = (tuple(sorted((k, str(v)) for k, v in kwargs.items())), None if seqs is None else (len(seqs), hash(tuple(seqs))))
+    cur = getattr(_CTX_TLS, "entry", None)
+    if os.environ.get("F2Q_NO_CTX_CACHE") == "1":              # A/B runs: a fresh context per sample
+        key = (key, object())
+    if cur is not None and cur[0] == _CTX_GEN[0] and cur[1] == key:
+        cur[2].reset()
+        return cur[2]
+    if cur is not None and cur[0] == _CTX_GEN[0]:
+        _drop_context(cur[2])
+    ctx = binding.Counter(features=seqs, **kwargs)
+    _CTX_TLS.entry = (_CTX_GEN[0], key, ctx)
+    with _CTX_LOCK:
+        _CTX_ALL.append(ctx)
+    return ctx
+
+
+def _drop_context(ctx):
+    with _CTX_LOCK:
+        if ctx in _CTX_ALL:
+            _CTX_ALL.remove(ctx)
+    _CTX_TLS.entry = None
+    ctx.close()
+
+
+def close_contexts():
+    """close every context kept by reads_counter (end of a run; also registered with atexit)"""
+    with _CTX_LOCK:
+        ctxs, _CTX_ALL[:] = list(_CTX_ALL), []
+        _CTX_GEN[0] += 1
+    for c in ctxs:
+        c.close()
+
+
+atexit.register(close_contexts)
+
+
 def reads_counter(i, raw, features, param, reads_stats, preprocess=False):
     """Counts one FASTQ(.gz) file (:514-582).  Returns (features, reads_stats, local_read_stats) -- the reference's
     contract.  A cut-off or damaged .gz gives the counts of every complete record before the damage plus the
@@ -120,7 +170,8 @@ def reads_counter(i, raw, features, param, reads_stats, preprocess=False):
         return features, reads_stats, local_read_stats
     counter_mode = param['Running Mode'] == 'C'
     seqs = list(features) if counter_mode else None
-    with binding.Counter(features=seqs, **_counter_kwargs(param)) as ctx:
+    ctx = _context_for(seqs, _counter_kwargs(param))
+    try:
         world = sharding.world()
         if world.size > 1:
             truncated = sharding.count_file_sharded(ctx, raw, world)
@@ -129,6 +180,9 @@ def reads_counter(i, raw, features, param, reads_stats, preprocess=False):
             _, truncated = ctx.count_file(raw)
             counts, stats = ctx.read_counts()
             ec_rows = None if counter_mode else ctx.ec_results()
+    except BaseException:
+        _drop_context(ctx)                          # whatever state the failure left: the next sample starts afresh
+        raise
     if truncated:
         colourful_errors("WARNING", f"{raw} is an incomplete or corrupted gzip file. Only partial processing might have occurred.")
     if counter_mode:
@@ -379,6 +433,13 @@ def aligner_mp_dispenser(features, param, start=0):
 
     files = list(enumerate(param['sequencing_files']['files']))
     workers = min(int(param.get("cpu") or 1), len(files), 16)
+    try:
+        _dispense(files, workers, one)
+    finally:
+        close_contexts()                            # (the worker threads' contexts outlive the threads otherwise)
+
+
+def _dispense(files, workers, one):
     if workers > 1 and sharding.world().size == 1:
         # --cp samples in flight, as upstream (:1646-1655) -- threads, not processes: the per-read work is in the
         # library (ctypes drops the GIL), each sample has its own context and HIP stream, and for .gz input the
@@ -543,7 +604,8 @@ def run_stats(headers, param, compiled, head, ordered):
         plt.close(fig)
 
     violin(per_sample, base + "_distribution_plot.png", 'Reads per feature distribution')
-    rpm = [[v / sum(d) * 1000000 for v in d] for d in per_sample if sum(d) > 0]
+    totals = [sum(d) for d in per_sample]                      # (once per sample: the inner sum made this step quadratic in the library size)
+    rpm = [[v / t * 1000000 for v in d] for d, t in zip(per_sample, totals) if t > 0]
     violin(rpm if len(rpm) == len(per_sample) else [], base + "_distribution_normalized_RPM_plot.png",
            'Reads per feature (RPM normalized) distribution')
 

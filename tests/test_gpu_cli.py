@@ -294,6 +294,33 @@ def test_cli_test_mode_end_to_end(tmp_path, monkeypatch):
     assert (subdirs[0] / "compiled.csv").read_bytes().count(b"\r\n") == len(rows)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["C", "EC"])
+def test_contexts_are_kept_between_samples(tmp_path, monkeypatch, mode):
+    """reads_counter keeps its context from one sample to the next (library index, staging buffers): every sample must
+    still start from zeroed counters and empty Extract+Count tables; F2Q_NO_CTX_CACHE=1 is the fresh-context path"""
+    guides = synth.make_library(80, 20, 45)
+    param = dict(fast2q.initializer(fast2q.input_parser(["-c", "--s", str(tmp_path), "--g", "x", "--o", str(tmp_path), "--mo", mode, "--m", "1"])))
+    files, want = [], []
+    for k, n in enumerate((1200, 300, 2500)):
+        fq = synth.make_fastq(synth.Spec(seed=60 + k, n_reads=n, read_len=60), guides)
+        (tmp_path / f"s{k}.fastq").write_bytes(fq)
+        orc = O.Oracle(features=[(g, g) for g in guides] if mode == "C" else None, mode=mode, miss=1)
+        orc.count_fastq(fq)
+        files.append(str(tmp_path / f"s{k}.fastq")); want.append((orc.counts(), orc.stats(), orc.keys() if mode == "EC" else None))
+    for env in ("", "1"):
+        monkeypatch.setenv("F2Q_NO_CTX_CACHE", env)
+        for f, (counts, stats, keys) in zip(files + files[:1], want + want[:1]):
+            feats = {g: fast2q.Features(g, 0) for g in guides} if mode == "C" else {}
+            feats, _, local = fast2q.reads_counter(0, f, feats, param, {})
+            assert [local[k] for k in fast2q.binding.STAT_NAMES] == stats
+            if mode == "C":
+                assert [feats[g].counts for g in guides] == counts
+            else:
+                assert list(feats) == keys and [v.counts for v in feats.values()] == counts
+        fast2q.close_contexts()
+
+
 def test_cli_directory_of_samples(tmp_path):
     guides = synth.make_library(60, 20, 44)
     (tmp_path / "in").mkdir()
