@@ -432,7 +432,12 @@ def aligner_mp_dispenser(features, param, start=0):
         aligner(i, raw, per_sample, param, reads_stats)
 
     files = list(enumerate(param['sequencing_files']['files']))
-    workers = min(int(param.get("cpu") or 1), len(files), 16)
+    # samples in flight: two.  The GPU counts a sample faster than the host reads it, the file reader brings its own
+    # worker pool (parallel pread / BGZF / gzip chunks), and every worker thread owns a context with pinned staging
+    # buffers: more threads only add allocations and contention (16 samples of 1 M reads, --cp 1 / 2 / 4 / 16: 1.7 / 1.7 /
+    # 2.1 / 2.4 s whole run; .gz: 2.4 / 2.0 / 2.4 / 3.1 s -- scripts/samples_threads.py).  F2Q_SAMPLES_IN_FLIGHT overrides.
+    cap = int(os.environ.get("F2Q_SAMPLES_IN_FLIGHT", "2") or 2)
+    workers = max(1, min(int(param.get("cpu") or 1), len(files), cap, 16))
     try:
         _dispense(files, workers, one)
     finally:

@@ -14,7 +14,7 @@ with pkg.Counter(features=guides, miss=1, phred=30, length=20, start="0") as c:
     for k in range(n_s):
         open(os.path.join(d, "fq", f"s{k:02d}.fastq"), "wb").write(bytes(c.synth_fastq(seed=100 + k, n_reads=n_r, read_len=150)))
 print("samples written", flush=True)
-args = ["-c", "--s", os.path.join(d, "fq"), "--g", os.path.join(d, "lib.csv"), "--o", os.path.join(d, "out"), "--m", "1", "--ph", "30", "--st", "0", "--l", "20", "--fn", "x"]
+args = ["-c", "--s", os.path.join(d, "fq"), "--g", os.path.join(d, "lib.csv"), "--o", os.path.join(d, "out"), "--m", "1", "--ph", "30", "--st", "0", "--l", "20", "--fn", "x", "--cp", "1"]
 f2q.main(list(args))                      # warm
 pr = cProfile.Profile(); pr.enable(); f2q.main(list(args)); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)

@@ -342,8 +342,12 @@ def test_cli_directory_of_samples(tmp_path):
         assert int(r[1]) == exp["s1"][r[0]] and int(r[2]) == exp["s2"][r[0]]
 
 
-def test_cli_samples_in_parallel_threads(tmp_path):
-    """--cp N: N samples in flight (threads over independent contexts); results identical to one at a time"""
+@pytest.mark.parametrize("in_flight", ["", "4", "1"])
+def test_cli_samples_in_parallel_threads(tmp_path, monkeypatch, in_flight):
+    """--cp N: samples in flight (threads over independent contexts, two by default, F2Q_SAMPLES_IN_FLIGHT overrides);
+    results identical to one at a time"""
+    if in_flight:
+        monkeypatch.setenv("F2Q_SAMPLES_IN_FLIGHT", in_flight)
     guides = synth.make_library(40, 20, 45)
     (tmp_path / "in").mkdir()
     csvp = tmp_path / "lib.csv"
