@@ -120,7 +120,7 @@ _CTX_GEN = [0]
 
 
 def _context_for(seqs, kwargs):
-    key = (tuple(sorted((k, str(v)) for k, v in kwargs.items())), None if seqs is None else (len(seqs), hash(tuple(seqs))))
+    key = (tuple(sorted((k, str(v)) for k, v in kwargs.items())), None if seqs is None else tuple(seqs))      # (compared by value: a few ms for 100 k features)
     cur = getattr(_CTX_TLS, "entry", None)
     if os.environ.get("F2Q_NO_CTX_CACHE") == "1":              # A/B runs: a fresh context per sample
         key = (key, object())
